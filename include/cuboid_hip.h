@@ -1,0 +1,190 @@
+/*
+ * cuboid_hip.h - C-ABI of libcuboid_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the per-frame point-cloud path of dash-robotics/perception:
+ *   crop -> voxel-downsample -> RANSAC ground plane -> extract -> Euclidean clusters ->
+ *   point-to-point ICP of each cluster against a template cuboid.
+ *
+ * The reference has no FFI of its own for this path: every numeric step is a PCL object
+ * used as "configure -> setInput -> one blocking compute call -> read outputs" inside the
+ * ROS callbacks.  Each entry point below replaces one such PCL call site; the citation
+ * next to it is the reference line it stands in for (paths relative to the reference
+ * repository root; gps.cpp = cuboid_detection/src/ground_plane_segmentation.cpp,
+ * icp.cpp = cuboid_detection/src/iterative_closest_point.cpp,
+ * opd.cpp = object_detection/src/object_pose_detection.cpp).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; caller owns every buffer; capacities are passed in and
+ *    counts are returned.  Point inputs are (base pointer, byte stride, count): x,y,z are
+ *    float32 at byte offsets 0/4/8 of each record, so pcl::PointXYZ (16 B),
+ *    pcl::PointXYZRGB (32 B) and raw sensor_msgs/PointCloud2 blobs pass without repacking.
+ *  - every function returns CD_OK (0) or a negative cd_status; nothing throws or aborts
+ *    across the boundary; cd_last_error() returns a message for the last failure.
+ *  - a context is NOT thread-safe (mirrors the reference's single ros::spin() thread,
+ *    gps.cpp:153); distinct contexts are independent (one per GPU / per process).
+ *  - there is no CPU fallback: if no HIP device is usable cd_create() fails with
+ *    CD_ERR_DEVICE and nothing else can be called.
+ *  - results are a pure function of the inputs (the only randomness is PCL's fixed-seed
+ *    RANSAC sampler, re-seeded per frame exactly as PCL does).
+ */
+#ifndef CUBOID_HIP_H
+#define CUBOID_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CD_ABI_VERSION 1
+#define CD_MAX_TEMPLATES 8          /* template slots per context (BASELINE config 5 uses 5) */
+#define CD_MAX_CLUSTERS_PER_FRAME 8 /* cluster slots in the fixed-size per-frame record      */
+
+typedef struct cd_context cd_context;
+
+typedef enum cd_status {
+    CD_OK = 0,
+    CD_ERR_INVALID_ARG = -1,   /* null pointer, bad stride, count out of range             */
+    CD_ERR_CAPACITY = -2,      /* input larger than the context / output buffer too small   */
+    CD_ERR_DEVICE = -3,        /* HIP runtime error or no usable device                     */
+    CD_ERR_NO_MODEL = -4,      /* RANSAC found no plane (PCL: empty inliers+coefficients)   */
+    CD_ERR_FEW_CORRESPONDENCES = -5, /* ICP source has < 3 points (PCL: "Not enough correspondences") */
+    CD_ERR_LEAF_TOO_SMALL = -6,/* voxel grid would overflow int32 indices (PCL warns)       */
+    CD_ERR_NO_TEMPLATE = -7    /* template slot empty                                       */
+} cd_status;
+
+/* Parameters of the whole chain.  Defaults (cd_default_params) are the cuboid_detection
+ * launch values with object_detection's clustering constants. */
+typedef struct cd_params {
+    /* S0 PassThrough "z" then "x" (gps.cpp:53-65, opd.cpp:273-289); limits inclusive, double */
+    double crop_z_min, crop_z_max;      /* 0.0, 0.9  */
+    double crop_x_min, crop_x_max;      /* -0.2, 0.2 */
+    /* S1 VoxelGrid leaf (gps.cpp:72; launch: 0.005 cuboid / 0.001 object) */
+    float leaf_size;
+    int32_t rgb_offset;                 /* byte offset of packed rgb in a record, -1 = none */
+    /* S2 SACSegmentation PLANE/RANSAC (gps.cpp:85-89) */
+    double plane_distance_threshold;    /* launch: 0.015 */
+    int32_t plane_max_iterations;       /* 1000 */
+    int32_t plane_optimize;             /* setOptimizeCoefficients(true) */
+    double plane_probability;           /* PCL default 0.99 */
+    /* S3 ExtractIndices (gps.cpp:100): 1 keeps the non-plane points */
+    int32_t extract_negative;
+    /* S3b second PassThrough "z" on the extracted cloud (opd.cpp:331-336); 0 disables */
+    int32_t crop2_enable;
+    double crop2_z_min, crop2_z_max;    /* 0.0, 0.75 */
+    /* S5 EuclideanClusterExtraction (opd.cpp:356-358); cluster_enable=0 feeds the whole
+     * extracted cloud to ICP as one source (the cuboid_detection flavour, icp.cpp:156,171) */
+    int32_t cluster_enable;
+    int32_t cluster_min_size, cluster_max_size; /* 200, 25000 */
+    double cluster_tolerance;           /* 0.02 */
+    /* S6 IterativeClosestPoint (icp.cpp:173-176, opd.cpp:223-226) */
+    int32_t icp_max_iterations;         /* 5000 */
+    int32_t template_slot;
+    double icp_transformation_epsilon;  /* 1e-9 */
+    double icp_euclidean_fitness_epsilon; /* = icp_fitness_score param, 0.0004 (relative MSE) */
+    double icp_accept_fitness;          /* acceptance test of icp.cpp:182, 0.0004 */
+} cd_params;
+
+/* One ICP result: what icp.cpp:178-182 / opd.cpp:228-235 read back from PCL. */
+typedef struct cd_cluster_result {
+    int32_t size;          /* N_s, points in the cluster                              */
+    int32_t iterations;    /* nr_iterations_                                          */
+    int32_t converged;     /* icp.hasConverged()                                      */
+    int32_t accepted;      /* converged && fitness < icp_accept_fitness (icp.cpp:182) */
+    float T[16];           /* getFinalTransformation(), row-major, scene -> template  */
+    double fitness;        /* getFitnessScore()                                       */
+    double pose[16];       /* T.cast<double>().inverse() (icp.cpp:179), row-major     */
+} cd_cluster_result;
+
+/* Fixed-size per-frame record (this is what is gathered across GPUs). */
+typedef struct cd_frame_result {
+    int32_t status;        /* cd_status of this frame                                 */
+    int32_t n_cropped;     /* N_c after S0                                            */
+    int32_t n_voxels;      /* N_v after S1                                            */
+    int32_t n_plane;       /* refined plane inliers (S2)                              */
+    int32_t n_objects;     /* N_o points after S3(+S3b)                               */
+    int32_t n_clusters;    /* K clusters found (may exceed the slots below)           */
+    int32_t ransac_iterations; /* PCL iterations_ consumed by the adaptive loop       */
+    int32_t reserved;
+    float plane[4];        /* refined coefficients a,b,c,d                            */
+    float pad[4];
+    cd_cluster_result clusters[CD_MAX_CLUSTERS_PER_FRAME]; /* size-descending          */
+} cd_frame_result;
+
+void cd_default_params(cd_params* p);
+int cd_abi_version(void);
+/* sizeof() of the ABI structs, for FFI layers to verify their mirror of this header:
+ * which = 0 cd_params, 1 cd_cluster_result, 2 cd_frame_result, 3 cd_timing. */
+int cd_struct_size(int which);
+
+/* Object lifetimes (replaces construction/destruction of the PCL objects and the node's
+ * globals, icp.cpp:26-46).  max_points = largest N per frame, max_frames = largest batch. */
+int cd_create(int device_id, int max_points, int max_frames, cd_context** out);
+void cd_destroy(cd_context* ctx);
+const char* cd_last_error(const cd_context* ctx);
+
+/* pcl::io::loadPCDFile + icp.setInputTarget (icp.cpp:159,172; opd.cpp:398,222): the
+ * template is uploaded once and stays device-resident. */
+int cd_set_template(cd_context* ctx, int slot, const void* xyz, size_t stride_bytes, int m);
+
+/* S0+S1: two PassThrough filters + VoxelGrid::filter (gps.cpp:53-73).  out_xyz receives
+ * N_v * 3 floats in ascending voxel-index order, out_rgb (may be NULL) N_v packed rgb. */
+int cd_crop_voxel(cd_context* ctx, const void* points, size_t stride_bytes, int n,
+                  const cd_params* prm, float* out_xyz, uint32_t* out_rgb, int capacity,
+                  int* out_n_cropped, int* out_n_voxels);
+
+/* S2: seg.segment(*inliers, *coefficients) (gps.cpp:93).  inliers ascending. */
+int cd_segment_plane(cd_context* ctx, const void* xyz, size_t stride_bytes, int n,
+                     const cd_params* prm, float coeff[4], int32_t* inliers, int capacity,
+                     int* out_n_inliers, int* out_iterations);
+
+/* S5: ec.extract(cluster_indices) (opd.cpp:362).  labels[i] = cluster rank (0 = largest,
+ * ties -> smaller first member index) or -1; sizes[k] for k < min(K, sizes_capacity). */
+int cd_cluster(cd_context* ctx, const void* xyz, size_t stride_bytes, int n,
+               const cd_params* prm, int32_t* labels, int32_t* sizes, int sizes_capacity,
+               int* out_k);
+
+/* S6: icp.align + getFinalTransformation + hasConverged + getFitnessScore
+ * (icp.cpp:170-182).  aligned (may be NULL) receives n*3 floats. */
+int cd_icp(cd_context* ctx, int slot, const void* src_xyz, size_t stride_bytes, int n,
+           const cd_params* prm, cd_cluster_result* out, float* aligned);
+
+/* Whole chain, one call per batch: what opd.cpp:270-413 does per frame (this is what the
+ * frames/s metric times).  `frames` holds n_frames * points_per_frame records.
+ * plane_inliers / labels (may be NULL) receive per frame `points_per_frame` int32 slots:
+ * the refined plane inlier indices (into the voxel cloud, ascending, -1 padded) and the
+ * cluster label of every point of the extracted cloud (-1 padded). */
+int cd_process_batch(cd_context* ctx, const void* frames, size_t stride_bytes,
+                     int points_per_frame, int n_frames, const cd_params* prm,
+                     cd_frame_result* results, int32_t* plane_inliers, int32_t* labels);
+
+/* Same, input already resident in device memory (HBM) of the context's GPU. */
+int cd_process_batch_device(cd_context* ctx, const void* d_frames, size_t stride_bytes,
+                            int points_per_frame, int n_frames, const cd_params* prm,
+                            cd_frame_result* results, int32_t* plane_inliers,
+                            int32_t* labels);
+
+/* S7 helpers: tf::Matrix3x3::getRotation + position (icp.cpp:55-82) and the 8 bbox
+ * corners in the order of icp.cpp:99-106 transformed by pose.cast<float>() (icp.cpp:110). */
+void cd_pose_to_position_quaternion(const double pose[16], double position[3],
+                                    double quat_xyzw[4]);
+void cd_bbox_corners(const double pose[16], double length, double width, double height,
+                     float corners_xyz[24]);
+
+/* Timing of the last cd_process_batch* call, milliseconds per stage measured with HIP
+ * events on the context's stream: [0] crop+voxel, [1] plane, [2] extract+cluster,
+ * [3] icp, [4] total device time.  Also the ICP kernel's launch count and summed time. */
+typedef struct cd_timing {
+    float stage_ms[5];
+    float icp_kernel_ms;
+    int32_t icp_kernel_launches;
+    int32_t icp_pair_tests_lo, icp_pair_tests_hi; /* 64-bit count of point-pair distance tests */
+    int64_t algorithmic_bytes;                    /* B_alg of SURVEY 8(d) for this batch */
+} cd_timing;
+int cd_get_timing(const cd_context* ctx, cd_timing* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUBOID_HIP_H */

@@ -1,0 +1,278 @@
+"""ctypes binding of libcuboid_hip.so (the C-ABI declared in include/cuboid_hip.h).
+
+This is the only way Python reaches the HIP path; there is no CPU fallback.  Loading
+fails loudly when the shared library has not been built (run `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C perception_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+CD_MAX_TEMPLATES = 8
+CD_MAX_CLUSTERS_PER_FRAME = 8
+
+CD_OK = 0
+CD_ERR_INVALID_ARG = -1
+CD_ERR_CAPACITY = -2
+CD_ERR_DEVICE = -3
+CD_ERR_NO_MODEL = -4
+CD_ERR_FEW_CORRESPONDENCES = -5
+CD_ERR_LEAF_TOO_SMALL = -6
+CD_ERR_NO_TEMPLATE = -7
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcuboid_hip.so")
+
+# every symbol include/cuboid_hip.h declares (checked by tests/test_abi.py)
+EXPORTED_SYMBOLS = [
+    "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
+    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_cluster", "cd_icp",
+    "cd_process_batch", "cd_process_batch_device", "cd_pose_to_position_quaternion",
+    "cd_bbox_corners", "cd_get_timing",
+]
+
+
+class CdParams(C.Structure):
+    _fields_ = [
+        ("crop_z_min", C.c_double), ("crop_z_max", C.c_double),
+        ("crop_x_min", C.c_double), ("crop_x_max", C.c_double),
+        ("leaf_size", C.c_float), ("rgb_offset", C.c_int32),
+        ("plane_distance_threshold", C.c_double),
+        ("plane_max_iterations", C.c_int32), ("plane_optimize", C.c_int32),
+        ("plane_probability", C.c_double),
+        ("extract_negative", C.c_int32), ("crop2_enable", C.c_int32),
+        ("crop2_z_min", C.c_double), ("crop2_z_max", C.c_double),
+        ("cluster_enable", C.c_int32),
+        ("cluster_min_size", C.c_int32), ("cluster_max_size", C.c_int32),
+        ("cluster_tolerance", C.c_double),
+        ("icp_max_iterations", C.c_int32), ("template_slot", C.c_int32),
+        ("icp_transformation_epsilon", C.c_double),
+        ("icp_euclidean_fitness_epsilon", C.c_double),
+        ("icp_accept_fitness", C.c_double),
+    ]
+
+
+class CdClusterResult(C.Structure):
+    _fields_ = [
+        ("size", C.c_int32), ("iterations", C.c_int32),
+        ("converged", C.c_int32), ("accepted", C.c_int32),
+        ("T", C.c_float * 16), ("fitness", C.c_double), ("pose", C.c_double * 16),
+    ]
+
+
+class CdFrameResult(C.Structure):
+    _fields_ = [
+        ("status", C.c_int32), ("n_cropped", C.c_int32), ("n_voxels", C.c_int32),
+        ("n_plane", C.c_int32), ("n_objects", C.c_int32), ("n_clusters", C.c_int32),
+        ("ransac_iterations", C.c_int32), ("reserved", C.c_int32),
+        ("plane", C.c_float * 4), ("pad", C.c_float * 4),
+        ("clusters", CdClusterResult * CD_MAX_CLUSTERS_PER_FRAME),
+    ]
+
+
+class CdTiming(C.Structure):
+    _fields_ = [
+        ("stage_ms", C.c_float * 5), ("icp_kernel_ms", C.c_float),
+        ("icp_kernel_launches", C.c_int32),
+        ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32),
+        ("algorithmic_bytes", C.c_int64),
+    ]
+
+
+FRAME_RESULT_BYTES = C.sizeof(CdFrameResult)
+
+
+def default_params():
+    """cuboid_detection launch values (ground_plane_segmentation.launch:14-18,
+    iterative_closest_point.launch:39-42) + object_detection's cluster constants
+    (object_pose_detection.cpp:356-358).  Pure Python mirror of cd_default_params()."""
+    p = CdParams()
+    p.crop_z_min, p.crop_z_max = 0.0, 0.9
+    p.crop_x_min, p.crop_x_max = -0.2, 0.2
+    p.leaf_size = 0.005
+    p.rgb_offset = -1
+    p.plane_distance_threshold = 0.015
+    p.plane_max_iterations = 1000
+    p.plane_optimize = 1
+    p.plane_probability = 0.99
+    p.extract_negative = 1
+    p.crop2_enable = 1
+    p.crop2_z_min, p.crop2_z_max = 0.0, 0.75
+    p.cluster_enable = 1
+    p.cluster_min_size, p.cluster_max_size = 200, 25000
+    p.cluster_tolerance = 0.02
+    p.icp_max_iterations = 5000
+    p.template_slot = 0
+    p.icp_transformation_epsilon = 1e-9
+    p.icp_euclidean_fitness_epsilon = 0.0004
+    p.icp_accept_fitness = 0.0004
+    return p
+
+
+_lib = None
+
+
+def load_library(path=None):
+    """dlopen libcuboid_hip.so and set prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise RuntimeError(
+            "libcuboid_hip.so not found at %s: the HIP extension is not built and there is "
+            "no CPU fallback (build with `make -C perception_amd/csrc`)" % p)
+    lib = C.CDLL(p)
+    vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    ip = C.POINTER(C.c_int)
+    lib.cd_default_params.argtypes = [C.POINTER(CdParams)]
+    lib.cd_default_params.restype = None
+    lib.cd_abi_version.restype = C.c_int
+    lib.cd_struct_size.argtypes = [C.c_int]
+    lib.cd_struct_size.restype = C.c_int
+    lib.cd_create.argtypes = [C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    lib.cd_destroy.argtypes = [vp]
+    lib.cd_destroy.restype = None
+    lib.cd_last_error.argtypes = [vp]
+    lib.cd_last_error.restype = C.c_char_p
+    lib.cd_set_template.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int]
+    lib.cd_crop_voxel.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp,
+                                  C.c_int, ip, ip]
+    lib.cd_segment_plane.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp,
+                                     C.c_int, ip, ip]
+    lib.cd_cluster.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp, C.c_int, ip]
+    lib.cd_icp.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(CdParams),
+                           C.POINTER(CdClusterResult), vp]
+    for f in (lib.cd_process_batch, lib.cd_process_batch_device):
+        f.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(CdParams), vp, vp, vp]
+    lib.cd_pose_to_position_quaternion.argtypes = [C.POINTER(C.c_double)] * 3
+    lib.cd_pose_to_position_quaternion.restype = None
+    lib.cd_bbox_corners.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, f32p]
+    lib.cd_bbox_corners.restype = None
+    lib.cd_get_timing.argtypes = [vp, C.POINTER(CdTiming)]
+    if path is None:
+        _lib = lib
+    return lib
+
+
+class CuboidError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("cd status %d: %s" % (status, msg))
+        self.status = status
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _points(a):
+    """(base pointer, stride, n) of a 2-D float32 array whose rows start with x,y,z."""
+    a = np.ascontiguousarray(a, dtype=np.float32) if a.dtype != np.float32 or not a.flags.c_contiguous else a
+    assert a.ndim == 2 and a.shape[1] >= 3
+    return a, a.strides[0], a.shape[0]
+
+
+class Context:
+    """One GPU context (cd_create/cd_destroy).  Not thread-safe, like the reference node."""
+
+    def __init__(self, max_points, max_frames=1, device_id=0):
+        self.lib = load_library()
+        h = C.c_void_p()
+        st = self.lib.cd_create(device_id, int(max_points), int(max_frames), C.byref(h))
+        if st != CD_OK:
+            raise CuboidError(st, "cd_create failed (no usable HIP device? there is no CPU fallback)")
+        self.h = h
+        self.max_points, self.max_frames = int(max_points), int(max_frames)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.cd_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, st, ok=(CD_OK,)):
+        if st not in ok:
+            raise CuboidError(st, (self.lib.cd_last_error(self.h) or b"").decode())
+        return st
+
+    def set_template(self, slot, xyz):
+        a, stride, m = _points(xyz)
+        self._check(self.lib.cd_set_template(self.h, slot, _ptr(a), stride, m))
+
+    def crop_voxel(self, points, prm, want_rgb=False):
+        a, stride, n = _points(points)
+        out = np.empty((n, 3), np.float32)
+        rgb = np.empty(n, np.uint32) if want_rgb else None
+        nc, nv = C.c_int(), C.c_int()
+        self._check(self.lib.cd_crop_voxel(self.h, _ptr(a), stride, n, C.byref(prm), _ptr(out), _ptr(rgb),
+                                           n, C.byref(nc), C.byref(nv)))
+        return out[:nv.value].copy(), (rgb[:nv.value].copy() if want_rgb else None), nc.value
+
+    def segment_plane(self, xyz, prm):
+        a, stride, n = _points(xyz)
+        coeff = np.zeros(4, np.float32)
+        inl = np.empty(max(n, 1), np.int32)
+        ni, it = C.c_int(), C.c_int()
+        st = self.lib.cd_segment_plane(self.h, _ptr(a), stride, n, C.byref(prm), _ptr(coeff), _ptr(inl), n,
+                                       C.byref(ni), C.byref(it))
+        self._check(st, ok=(CD_OK, CD_ERR_NO_MODEL))
+        return st, coeff, inl[:ni.value].copy(), it.value
+
+    def cluster(self, xyz, prm, sizes_capacity=4096):
+        a, stride, n = _points(xyz)
+        labels = np.empty(max(n, 1), np.int32)
+        sizes = np.zeros(sizes_capacity, np.int32)
+        k = C.c_int()
+        self._check(self.lib.cd_cluster(self.h, _ptr(a), stride, n, C.byref(prm), _ptr(labels), _ptr(sizes),
+                                        sizes_capacity, C.byref(k)))
+        return labels[:n].copy(), sizes[:min(k.value, sizes_capacity)].copy(), k.value
+
+    def icp(self, slot, src, prm, want_aligned=False):
+        a, stride, n = _points(src)
+        res = CdClusterResult()
+        al = np.empty((n, 3), np.float32) if want_aligned else None
+        st = self.lib.cd_icp(self.h, slot, _ptr(a), stride, n, C.byref(prm), C.byref(res), _ptr(al))
+        self._check(st, ok=(CD_OK, CD_ERR_FEW_CORRESPONDENCES))
+        return st, res, al
+
+    def process_batch(self, frames, prm, want_indices=False):
+        """frames: (F, N, C>=3) float32 host array.  Returns (results, plane_inliers, labels)."""
+        f = np.ascontiguousarray(frames, dtype=np.float32)
+        assert f.ndim == 3
+        F, N, Cc = f.shape
+        res = (CdFrameResult * F)()
+        pi = np.empty((F, N), np.int32) if want_indices else None
+        lb = np.empty((F, N), np.int32) if want_indices else None
+        self._check(self.lib.cd_process_batch(self.h, _ptr(f), Cc * 4, N, F, C.byref(prm),
+                                              C.cast(res, C.c_void_p), _ptr(pi), _ptr(lb)))
+        return res, pi, lb
+
+    def process_batch_device(self, dev_ptr, stride_bytes, points_per_frame, n_frames, prm,
+                             results=None, plane_inliers=None, labels=None):
+        """Input already in HBM (e.g. a torch tensor's data_ptr())."""
+        res = results if results is not None else (CdFrameResult * n_frames)()
+        self._check(self.lib.cd_process_batch_device(self.h, C.c_void_p(dev_ptr), stride_bytes,
+                                                     points_per_frame, n_frames, C.byref(prm),
+                                                     C.cast(res, C.c_void_p), _ptr(plane_inliers),
+                                                     _ptr(labels)))
+        return res
+
+    def timing(self):
+        t = CdTiming()
+        self._check(self.lib.cd_get_timing(self.h, C.byref(t)))
+        return t
+
+
+def results_to_array(res):
+    """View an array of CdFrameResult as a uint8 numpy array (F, FRAME_RESULT_BYTES)."""
+    n = len(res)
+    return np.frombuffer(res, dtype=np.uint8).reshape(n, FRAME_RESULT_BYTES)
+
+
+def results_from_array(arr):
+    arr = np.ascontiguousarray(arr, dtype=np.uint8)
+    n = arr.shape[0]
+    out = (CdFrameResult * n)()
+    C.memmove(out, arr.ctypes.data, n * FRAME_RESULT_BYTES)
+    return out

@@ -1,0 +1,285 @@
+"""Known-answer tests of the oracle's stages (analytic cases; PCL semantics of SURVEY 8a)."""
+import numpy as np
+import pytest
+
+from conftest import rot_xyz
+from perception_amd import capi
+
+
+def _mt19937_py(seed, n):
+    mt = [0] * 624
+    mt[0] = seed & 0xFFFFFFFF
+    for i in range(1, 624):
+        mt[i] = (1812433253 * (mt[i - 1] ^ (mt[i - 1] >> 30)) + i) & 0xFFFFFFFF
+    out, idx = [], 624
+    for _ in range(n):
+        if idx >= 624:
+            for k in range(624):
+                y = (mt[k] & 0x80000000) | (mt[(k + 1) % 624] & 0x7FFFFFFF)
+                mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ (0x9908B0DF if y & 1 else 0)
+            idx = 0
+        y = mt[idx]
+        idx += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        out.append(y & 0xFFFFFFFF)
+    return np.array(out, dtype=np.uint32)
+
+
+def test_mt19937_known_answers(O):
+    assert O.mt19937_stream(5489, 10000)[-1] == 4123659995      # ISO C++ [rand.predef]
+    s = O.mt19937_stream(12345, 2000)                           # PCL's fixed SAC seed
+    assert np.array_equal(s, _mt19937_py(12345, 2000))
+
+
+def test_passthrough_limits_are_double(O):
+    f = np.float32
+    vals = np.array([0.2, np.nextafter(f(0.2), f(0)), np.nextafter(f(0.2), f(1)), -0.2,
+                     np.nextafter(f(-0.2), f(0)), np.nan, np.inf, 0.0, -0.0], dtype=np.float32)
+    pts = np.zeros((len(vals), 3), np.float32)
+    pts[:, 0] = vals
+    keep = O.passthrough(pts, 0, -0.2, 0.2)
+    # float32(0.2) = 0.200000003 > 0.2 (double) -> rejected; float32(-0.2) < -0.2 -> rejected
+    assert list(keep) == [1, 4, 7, 8]
+    pts2 = np.ones((3, 3), np.float32)
+    pts2[1, 1] = np.nan            # non-finite y drops the point even if the field is fine
+    assert list(O.passthrough(pts2, 2, 0.0, 1.0)) == [0, 2]
+
+
+def test_voxel_grid_order_and_centroid(O, prm):
+    prm.leaf_size = 0.1
+    pts = np.array([[0.05, 0.05, 0.55], [0.16, 0.05, 0.55], [0.04, 0.06, 0.56], [0.05, 0.15, 0.55],
+                    [0.05, 0.05, 0.65], [0.5, 0.0, 0.5], [0.0, 0.0, 2.0], [np.nan, 0, 0.5]], np.float32)
+    st, vox, _, nc, grid = O.crop_voxel(pts, prm)
+    assert st == 0 and nc == 5
+    assert list(grid[3:]) == [2, 2, 2]
+    # ascending idx = x fastest, then y, then z
+    c0 = (pts[0] + pts[2]) / np.float32(2)
+    exp = np.array([c0, pts[1], pts[3], pts[4]], np.float32)
+    assert np.array_equal(vox, exp)
+
+
+def test_voxel_rgb_average(O, prm):
+    prm.leaf_size = 0.1
+    prm.rgb_offset = 12
+    pts = np.zeros((3, 4), np.float32)
+    pts[:, :3] = [[0.01, 0.01, 0.51], [0.02, 0.02, 0.52], [0.03, 0.01, 0.53]]
+    pts[:, 3] = np.array([(10 << 16) | (20 << 8) | 30, (11 << 16) | (21 << 8) | 33, (13 << 16) | (25 << 8) | 30],
+                         np.uint32).view(np.float32)
+    st, vox, rgb, nc, _ = O.crop_voxel(pts, prm, want_rgb=True)
+    assert st == 0 and len(vox) == 1
+    assert rgb[0] == (11 << 16) | (22 << 8) | 31       # (34/3, 66/3, 93/3) truncated
+
+
+def test_voxel_leaf_too_small(O, prm):
+    prm.leaf_size = 1e-5
+    pts = np.array([[-0.19, -5, 0.1], [0.19, 5, 0.89]], np.float32)
+    st, *_ = O.crop_voxel(pts, prm)
+    assert st == capi.CD_ERR_LEAF_TOO_SMALL
+
+
+def _plane_cloud(n_in=3000, n_out=400, seed=1):
+    rng = np.random.RandomState(seed)
+    nrm = np.array([0.1, -0.7, -0.7])
+    nrm /= np.linalg.norm(nrm)
+    e1 = np.cross(nrm, [1, 0, 0.3])
+    e1 /= np.linalg.norm(e1)
+    e2 = np.cross(nrm, e1)
+    p0 = np.array([0, 0, 0.55])
+    ab = rng.uniform(-0.3, 0.3, (n_in, 2))
+    P = p0 + ab[:, :1] * e1 + ab[:, 1:] * e2
+    h = rng.uniform(0.05, 0.3, n_out) * rng.choice([-1, 1], n_out)
+    ab2 = rng.uniform(-0.3, 0.3, (n_out, 2))
+    Q = p0 + ab2[:, :1] * e1 + ab2[:, 1:] * e2 + h[:, None] * nrm
+    pts = np.concatenate([P, Q]).astype(np.float32)
+    perm = rng.permutation(len(pts))
+    truth = np.zeros(len(pts), bool)
+    truth[:n_in] = True
+    return pts[perm], truth[perm], nrm, -nrm @ p0
+
+
+def test_plane_exact_inliers(O, prm):
+    pts, truth, nrm, d = _plane_cloud()
+    st, coeff, inl, iters = O.segment_plane(pts, prm)
+    assert st == 0
+    assert np.array_equal(inl, np.nonzero(truth)[0])
+    s = np.sign(coeff[:3] @ nrm)
+    assert np.abs(s * coeff[:3] - nrm).max() < 1e-5 and abs(s * coeff[3] - d) < 1e-5
+    # adaptive stop: w = 0.88 -> k = ln(0.01)/ln(1-w^3) ~ 4: a handful of iterations, not 1000
+    assert 1 <= iters <= 12
+    assert abs(np.linalg.norm(coeff[:3]) - 1) < 1e-6
+
+
+def test_plane_trace_and_adaptive_replay(O, prm):
+    """Hypotheses are a fixed function of (seed, N): replaying PCL's k-logic over the traced
+    counts reproduces the iteration count segment_plane reports."""
+    pts, truth, *_ = _plane_cloud(seed=3)
+    tri, mod, cnt = O.ransac_trace(pts, prm, 64)
+    assert len(tri) == 64 and tri.min() >= 0 and tri.max() < len(pts)
+    assert all(len(set(t)) == 3 for t in tri.tolist())
+    st, coeff, inl, iters = O.segment_plane(pts, prm)
+    k, best, it = 1.0, -2**31, 0
+    for c in cnt:
+        if not (it < k):
+            break
+        if c < 0:
+            continue
+        if c > best:
+            best = c
+            w = best / len(pts)
+            p = min(max(1 - w ** 3, np.finfo(float).eps), 1 - np.finfo(float).eps)
+            k = np.log(1 - 0.99) / np.log(p)
+        it += 1
+    assert it == iters
+
+
+def test_plane_no_model(O, prm):
+    st, coeff, inl, iters = O.segment_plane(np.zeros((2, 3), np.float32), prm)
+    assert st == capi.CD_ERR_NO_MODEL and len(inl) == 0
+    # Axis-aligned collinear points: PCL's ratio test sees 0/0 = NaN != x and lets the sample
+    # through; the cross product is 0, normalize() gives NaN, nothing is ever an inlier, w = 0
+    # keeps k huge and the loop runs to max_iterations + 1.  PCL reports success with NaN
+    # coefficients and no inliers; so does the restatement.
+    line = np.zeros((50, 3), np.float32)
+    line[:, 0] = np.arange(50) * 0.01
+    st, coeff, inl, iters = O.segment_plane(line, prm)
+    assert st == 0 and len(inl) == 0 and np.isnan(coeff).all() and iters == 1001
+    # Collinear along a diagonal: all three ratios are equal -> samples rejected -> no model
+    diag = np.outer(np.arange(1, 51), [0.01, 0.02, 0.03]).astype(np.float32)
+    st, coeff, inl, iters = O.segment_plane(diag, prm)
+    assert len(inl) == 0
+
+
+def test_eigen33_vs_numpy(O):
+    rng = np.random.RandomState(0)
+    for _ in range(20):
+        A = rng.randn(3, 3)
+        cov = (A @ np.diag([1.0, 0.3, 0.01]) @ A.T).astype(np.float32)
+        v = O.eigen33_smallest(cov)
+        w, V = np.linalg.eigh(cov.astype(np.float64))
+        assert abs(abs(v @ V[:, 0]) - 1) < 2e-3
+
+
+def test_svd3(O):
+    rng = np.random.RandomState(1)
+    mats = [rng.randn(3, 3).astype(np.float32) for _ in range(20)]
+    mats += [np.zeros((3, 3), np.float32), np.diag([3, 2, 0]).astype(np.float32),
+             np.outer([1, 2, 3], [0.5, -1, 2]).astype(np.float32)]
+    for A in mats:
+        U, S, V = O.svd3(A)
+        assert np.abs(U @ np.diag(S) @ V.T - A).max() < 2e-5 * max(1, np.abs(A).max())
+        assert np.abs(U @ U.T - np.eye(3)).max() < 1e-5 and np.abs(V @ V.T - np.eye(3)).max() < 1e-5
+        assert S[0] >= S[1] >= S[2] >= 0
+        assert np.abs(S - np.linalg.svd(A.astype(np.float64), compute_uv=False)).max() < 1e-5 * max(1, S[0])
+
+
+def _blob(center, n, r, rng):
+    return (np.asarray(center) + rng.uniform(-r, r, (n, 3))).astype(np.float32)
+
+
+def test_cluster_strict_radius_and_size_window(O, prm):
+    tol = np.float32(0.02)
+    # chain along x with gaps just below / exactly at the tolerance (strict <)
+    xs = np.cumsum([0, 0.019, 0.019, 0.02, 0.019], dtype=np.float64)
+    chain = np.zeros((5, 3), np.float32)
+    chain[:, 0] = xs
+    prm.cluster_min_size, prm.cluster_max_size = 1, 100
+    d2 = (chain[3, 0] - chain[2, 0]) ** 2
+    lab, sizes, k = O.cluster(chain, prm, mode=0)
+    if d2 < np.float32(0.02 * 0.02):      # float32 rounding decides; the predicate is the spec
+        assert k == 1
+    else:
+        assert k == 2 and list(sizes) == [3, 2] and list(lab) == [0, 0, 0, 1, 1]
+    rng = np.random.RandomState(5)
+    prm.cluster_min_size, prm.cluster_max_size = 200, 25000
+    a = _blob([0, 0, 0.5], 199, 0.01, rng)
+    b = _blob([0.2, 0, 0.5], 200, 0.01, rng)
+    c = _blob([0.4, 0, 0.5], 300, 0.01, rng)
+    pts = np.concatenate([a, b, c])
+    perm = rng.permutation(len(pts))
+    src = np.concatenate([np.full(199, -1), np.full(200, 1), np.full(300, 0)])[perm]
+    for mode in (0, 1):
+        lab, sizes, k = O.cluster(pts[perm], prm, mode=mode)
+        assert k == 2 and list(sizes) == [300, 200]
+        assert np.array_equal(lab, src)
+
+
+def test_cluster_max_size_drops_whole_component(O, prm):
+    g = np.stack(np.meshgrid(np.arange(160), np.arange(157)), -1).reshape(-1, 2) * 0.01
+    big = np.zeros((len(g), 3), np.float32)
+    big[:, :2] = g
+    assert len(big) == 25120
+    prm.cluster_max_size = 25119
+    lab, sizes, k = O.cluster(big, prm, mode=1)
+    assert k == 0 and (lab == -1).all()
+    prm.cluster_max_size = 25120
+    lab, sizes, k = O.cluster(big, prm, mode=1)
+    assert k == 1 and sizes[0] == 25120 and (lab == 0).all()
+
+
+def test_cluster_tie_break_and_grid_equals_brute(O, prm):
+    rng = np.random.RandomState(9)
+    prm.cluster_min_size = 5
+    pts = np.concatenate([_blob([0.3, 0, 0.5], 50, 0.012, rng), _blob([0, 0, 0.5], 50, 0.012, rng),
+                          rng.uniform(-0.5, 0.5, (600, 3)).astype(np.float32) * [1, 1, 0.05]])
+    l0, s0, k0 = O.cluster(pts, prm, mode=0)
+    l1, s1, k1 = O.cluster(pts, prm, mode=1)
+    assert k0 == k1 and np.array_equal(l0, l1) and np.array_equal(s0, s1)
+    assert all(s0[i] >= s0[i + 1] for i in range(len(s0) - 1))
+    # equal sizes: the component holding the smaller first index gets the smaller label
+    for a in range(k0 - 1):
+        if s0[a] == s0[a + 1]:
+            assert np.nonzero(l0 == a)[0][0] < np.nonzero(l0 == a + 1)[0][0]
+
+
+def test_nn_kdtree_equals_brute_with_ties(O, template):
+    rng = np.random.RandomState(2)
+    tgt = np.concatenate([template[::7], template[::7][:50]])      # duplicates -> exact ties
+    q = np.concatenate([rng.uniform(-0.6, 0.6, (500, 3)), tgt[:100] + 0.001, tgt[-20:]]).astype(np.float32)
+    i0, d0 = O.nn(tgt, q, mode=0)
+    i1, d1 = O.nn(tgt, q, mode=1)
+    assert np.array_equal(i0, i1) and np.array_equal(d0, d1)
+    assert (i0[-20:] < len(tgt) - 50).all()      # lowest index wins an exact tie
+
+
+def test_icp_recovers_known_transform(O, prm, template):
+    # Perturbation below half the template's 2 mm grid pitch: every nearest neighbour is the
+    # true correspondent, so point-to-point ICP must land on T_known (a larger offset settles
+    # in one of the grid's many local minima - PCL does too).
+    R = rot_xyz(np.deg2rad(0.2), np.deg2rad(-0.15), np.deg2rad(0.25))
+    t = np.array([0.0004, -0.0003, 0.0005])
+    Tk = np.eye(4)
+    Tk[:3, :3] = R
+    Tk[:3, 3] = t
+    src = (template[::3].astype(np.float64) @ R.T + t).astype(np.float32)    # pose == Tk
+    prm.icp_euclidean_fitness_epsilon = 1e-9       # tight: run to the fixed point
+    st, res, al = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert st == 0 and res.converged == 1
+    pose = np.array(res.pose).reshape(4, 4)
+    assert np.linalg.norm(pose - Tk) < 1e-4
+    assert res.fitness < 1e-10
+    T = np.array(res.T, np.float64).reshape(4, 4)
+    assert np.abs(T @ pose - np.eye(4)).max() < 1e-6
+    assert np.abs(al - template[::3]).max() < 1e-4
+
+
+def test_icp_few_points(O, prm, template):
+    st, res, _ = O.icp(template, template[:2], prm)
+    assert st == capi.CD_ERR_FEW_CORRESPONDENCES and res.converged == 0
+    assert list(res.T) == list(np.eye(4, dtype=np.float32).ravel())
+
+
+def test_icp_real_cluster_self_registration(O, prm):
+    """Real D435 cluster from the reference tree registered against a perturbed copy."""
+    import os
+    from conftest import GOLDEN
+    from perception_amd import pcd
+    X = pcd.read_xyz(os.path.join(GOLDEN, "eraser_ascii.pcd"))
+    R = rot_xyz(np.deg2rad(0.1), np.deg2rad(0.15), np.deg2rad(-0.1))     # sub-pixel-pitch offset
+    c = X.mean(0).astype(np.float64)
+    src = ((X - c) @ R.T + c + [0.0003, -0.0002, 0.0002]).astype(np.float32)
+    prm.icp_euclidean_fitness_epsilon = 1e-9
+    st, res, _ = O.icp(X, src, prm, nn_mode=1)
+    assert st == 0 and res.converged == 1 and res.fitness < 1e-10
