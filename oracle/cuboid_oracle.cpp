@@ -131,6 +131,9 @@ int voxel_grid(const Cloud& c, const std::vector<int>& idx, float leaf, int rgb_
         max_b[a] = (int)std::floor(mx[a] * inv);
         out.div_b[a] = max_b[a] - out.min_b[a] + 1;
     }
+    // (PCL's check above uses (max-min)*inv; the per-axis divisions can still multiply past
+    // int32 in the marginal case, where PCL would silently wrap.  Treated as the same error.)
+    if ((int64_t)out.div_b[0] * out.div_b[1] * out.div_b[2] > (int64_t)INT32_MAX) return CD_ERR_LEAF_TOO_SMALL;
     const int mul1 = out.div_b[0], mul2 = out.div_b[0] * out.div_b[1];
     std::vector<std::pair<int, int>> kv(idx.size());  // (voxel idx, cloud point index)
     for (size_t k = 0; k < idx.size(); ++k) {

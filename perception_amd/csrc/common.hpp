@@ -1,0 +1,125 @@
+// common.hpp - shared definitions of libcuboid_hip (device + host).  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cuboid_hip.h"
+
+namespace cd {
+
+constexpr int WAVE = 64;
+constexpr int BLOCK = 256;                 // 4 waves, one per SIMD
+constexpr int WAVES_PER_BLOCK = BLOCK / WAVE;
+constexpr int ITEMS = 8;                   // rows per wave in an ordered tile
+constexpr int TILE = BLOCK * ITEMS;        // 2048 elements; wave w owns [w*512,(w+1)*512)
+constexpr int WAVE_SPAN = WAVE * ITEMS;    // 512
+constexpr int RADIX_BITS = 8;
+constexpr int RADIX = 1 << RADIX_BITS;
+constexpr int KICP = CD_MAX_CLUSTERS_PER_FRAME;  // clusters per frame that get ICP
+constexpr int FIX_SHIFT = 32;              // canonical rule C4
+constexpr int FIX_SHIFT_D2 = 36;
+constexpr int RND_TABLE = 1 << 15;         // precomputed mt19937(12345)>>1 draws
+constexpr int SAMPLER_MAP = 8192;          // LDS sparse shuffle map (open addressing)
+constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses at most kept per frame
+constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
+constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
+
+// Per-frame scalars that live on the device and are mirrored to pinned host memory.
+struct FrameState {
+    int32_t status;        // cd_status
+    int32_t n_c;           // cropped points
+    uint32_t mn[3], mx[3]; // order-preserving uint encoding of min/max of the cropped cloud
+    int32_t min_b[3], div_b[3];
+    int32_t key_bits;      // bits needed for the voxel index
+    int32_t n_v;           // voxels
+    int32_t n_plane;       // refined plane inliers
+    int32_t n_o;           // extracted (object) points
+    int32_t n_k;           // clusters found
+    int32_t n_hyp;         // hypotheses generated so far by the sampler
+    int32_t sampler_exhausted;
+    int32_t ksize[KICP];   // sizes of the KICP largest clusters
+    int32_t koff[KICP];    // their offsets in the per-frame ICP source segment
+    float origin[3];       // decoded min of the cropped cloud
+    int32_t n_cropped;     // N_c as reported (n_c is zeroed when the frame errors out)
+};
+
+struct CropLimits {        // double limits folded to equivalent float compares (exact)
+    float zlo, zhi, xlo, xhi;
+};
+
+struct IcpCluster {        // static description of one ICP problem (host-built)
+    int32_t src_off;       // offset (points) into the ICP source buffers
+    int32_t n;
+    int32_t frame, k;
+    int32_t tpl_off, tpl_m;
+    int32_t tile0;         // first work item of this cluster
+    int32_t pad;
+};
+
+struct IcpState {          // dynamic ICP state, double-buffered by launch parity
+    float Tfinal[16];
+    double prev_mse;
+    int32_t iters;
+    int32_t done;
+    int32_t converged;
+    int32_t status;
+};
+
+struct IcpWork {
+    int32_t cluster, tile;
+};
+
+struct IcpParams {
+    int32_t max_iter;
+    int32_t pad;
+    double trans_eps, rel_mse, rot_thr, abs_mse;
+};
+
+// ---------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__host__ __device__ __forceinline__ float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+#ifdef __HIP_DEVICE_COMPILE__
+    return __uint_as_float(u);
+#else
+    float f;
+    __builtin_memcpy(&f, &u, 4);
+    return f;
+#endif
+}
+__device__ __forceinline__ uint64_t lanemask_lt() {
+    const uint32_t lane = threadIdx.x & 63;
+    return (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+}
+__device__ __forceinline__ long long fixq(float v, int shift) {
+    // float->double exact, power-of-two scale exact, round to nearest even (C4)
+    return __double2ll_rn(ldexp((double)v, shift));
+}
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// canonical squared distance: (dx*dx + dy*dy) + dz*dz, no contraction
+__device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+// canonical plane distance: |(a*x + b*y) + (c*z + d)|
+__device__ __forceinline__ float plane_dist(float a, float b, float c, float d, float x, float y, float z) {
+    return fabsf(__fadd_rn(__fadd_rn(__fmul_rn(a, x), __fmul_rn(b, y)), __fadd_rn(__fmul_rn(c, z), d)));
+}
+#endif
+
+}  // namespace cd

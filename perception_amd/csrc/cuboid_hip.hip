@@ -1,0 +1,780 @@
+// cuboid_hip.hip - context, batch pipeline driver and the C-ABI of include/cuboid_hip.h.
+//
+// The whole chain runs on one HIP stream with every intermediate resident in HBM
+// (frame-major arrays, pitch = points per frame).  The host only (a) sizes launches from a
+// handful of per-frame scalars mirrored through pinned memory, (b) replays PCL's sequential
+// RANSAC stop rule over the batched inlier counts, (c) solves the 3x3 plane-refit eigenproblem
+// and (d) polls ICP completion.  There is no CPU compute fallback of any stage.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "host_math.hpp"
+#include "kernels.hpp"
+
+using namespace cd;
+
+struct cd_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int N = 0, F = 0, T = 0;   // capacities: points per frame, frames, tiles per frame
+    char err[512] = {0};
+    // input staging (host-pointer API)
+    char* d_in = nullptr;
+    size_t d_in_bytes = 0;
+    // per-frame scalars
+    FrameState* d_fs = nullptr;
+    FrameState* h_fs = nullptr;
+    // ordered-compaction tile counters
+    int *d_tileA = nullptr, *d_tileB = nullptr, *d_tileK = nullptr;
+    // point buffers (float4 = x,y,z,rgb bits)
+    float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
+    uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_hist = nullptr;
+    // RANSAC
+    int* d_rnd = nullptr;
+    float4* d_models = nullptr;
+    int *d_valid = nullptr, *d_counts = nullptr, *d_active = nullptr;
+    int *h_valid = nullptr, *h_counts = nullptr, *h_active = nullptr;
+    float4 *d_model = nullptr, *h_model = nullptr;
+    int *d_have = nullptr, *h_have = nullptr;
+    unsigned long long *d_sums = nullptr, *h_sums = nullptr;
+    // extract / cluster
+    int *d_plane_idx = nullptr, *d_head = nullptr, *d_next = nullptr, *d_parent = nullptr, *d_csize = nullptr,
+        *d_rank = nullptr, *d_cand = nullptr, *d_sizes = nullptr, *d_label = nullptr;
+    // templates
+    float4* d_tpl = nullptr;
+    int tpl_cap = 0, tpl_used = 0;
+    int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
+    // ICP
+    IcpCluster *d_cl = nullptr, *h_cl = nullptr;
+    IcpWork *d_work = nullptr, *h_work = nullptr;
+    int work_cap = 0;
+    IcpState *d_st = nullptr, *h_st = nullptr;
+    unsigned long long *d_acc = nullptr, *d_accf = nullptr, *h_accf = nullptr;
+    hipEvent_t ev[8] = {nullptr};
+    cd_timing timing;
+};
+
+namespace {
+
+#define HIPCHK(ctx, expr)                                                                                   \
+    do {                                                                                                    \
+        hipError_t e_ = (expr);                                                                             \
+        if (e_ != hipSuccess) {                                                                             \
+            snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                                   \
+            return CD_ERR_DEVICE;                                                                           \
+        }                                                                                                   \
+    } while (0)
+
+int fail(cd_context* c, int code, const char* msg) {
+    snprintf(c->err, sizeof(c->err), "%s", msg);
+    return code;
+}
+
+template <class Tp>
+hipError_t dalloc(Tp** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp)); }
+template <class Tp>
+hipError_t halloc(Tp** p, size_t n) { return hipHostMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp), hipHostMallocDefault); }
+
+const int FS_PITCH = (int)(sizeof(FrameState) / sizeof(int));
+#define FS_FIELD(ctx, field) ((int*)((char*)(ctx)->d_fs + offsetof(FrameState, field)))
+
+int ensure_input(cd_context* c, size_t bytes) {
+    if (bytes <= c->d_in_bytes) return CD_OK;
+    if (c->d_in) hipFree(c->d_in);
+    c->d_in = nullptr;
+    c->d_in_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&c->d_in, bytes));
+    c->d_in_bytes = bytes;
+    return CD_OK;
+}
+
+int sync_fs(cd_context* c, int F) {
+    HIPCHK(c, hipMemcpyAsync(c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CD_OK;
+}
+
+// ---- stage drivers (device-resident in/out; F frames) ------------------------------------
+
+// S0+S1.  in: F*N records of `stride` bytes on the device.  out: d_vox / fs.n_v
+int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int F, const cd_params* p, int* rounds_out) {
+    const int T = c->T;
+    CropLimits lim;
+    lim.zlo = hm::fold_ge(p->crop_z_min);
+    lim.zhi = hm::fold_le(p->crop_z_max);
+    lim.xlo = hm::fold_ge(p->crop_x_min);
+    lim.xhi = hm::fold_le(p->crop_x_max);
+    const int rgb_off = (p->rgb_offset >= 0 && (size_t)p->rgb_offset + 4 <= stride) ? p->rgb_offset : -1;
+    // FrameState init: status 0, mn = +max, mx = 0 (ordered-uint encoding)
+    for (int f = 0; f < F; ++f) {
+        FrameState& s = c->h_fs[f];
+        std::memset(&s, 0, sizeof(s));
+        for (int a = 0; a < 3; ++a) { s.mn[a] = 0xffffffffu; s.mx[a] = 0u; }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+    launch_crop_count(c->stream, d_in, stride, N, F, rgb_off, lim, T, c->d_fs, c->d_tileA);
+    launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_c), FS_PITCH);
+    launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size);
+    launch_crop_compact(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]);
+    int st = sync_fs(c, F);   // sync #1: n_c, key_bits (sort pass count)
+    if (st) return st;
+    int max_nc = 0, max_bits = 0;
+    for (int f = 0; f < F; ++f) { max_nc = std::max(max_nc, c->h_fs[f].n_c); max_bits = std::max(max_bits, c->h_fs[f].key_bits); }
+    const int Tc = std::max(1, (max_nc + TILE - 1) / TILE);
+    int cur = 0;
+    const uint32_t* vin = nullptr;
+    for (int shift = 0; shift < max_bits; shift += RADIX_BITS) {
+        launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, T, Tc, shift, c->d_fs, c->d_hist);
+        cur ^= 1;
+        vin = c->d_val[cur];
+    }
+    if (!vin) {   // zero passes (empty frames only): identity permutation is never read
+        vin = c->d_val[cur];
+    }
+    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+    launch_voxel_heads_count(c->stream, c->d_key[cur], c->N, F, T, Tc, c->d_fs, c->d_tileA);
+    launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_v), FS_PITCH);
+    launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox);
+    if (rounds_out) *rounds_out = 0;
+    return CD_OK;
+}
+
+// S2.  in: d_vox + fs.n_v (host mirror h_fs[].n_v must be current).  out: h_model/h_have refined,
+// fs.status updated for NO_MODEL, iterations per frame.
+int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iterations, int* rounds_out) {
+    const int T = c->T;
+    const float thr = hm::fold_ge(p->plane_distance_threshold);
+    int max_nv = 0;
+    for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
+    const int Tv = std::max(1, (max_nv + TILE - 1) / TILE);
+    std::vector<hm::RansacReplay> rep(F);
+    iterations.assign(F, 0);
+    for (int f = 0; f < F; ++f) c->h_active[f] = (c->h_fs[f].status == CD_OK || c->h_fs[f].status == CD_ERR_NO_MODEL) ? 1 : 0;
+    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * (size_t)F * MAX_HYP, c->stream));
+    const int targets[4] = {16, 64, 256, MAX_HYP};
+    const int h_cap = std::min(MAX_HYP, p->plane_max_iterations + 40);   // max_iterations+1 plus 39 skipped models
+    int h_prev = 0, rounds = 0;
+    for (int r = 0; r < 4; ++r) {
+        const int h_target = std::min(targets[r], h_cap);
+        if (h_target <= h_prev) break;
+        HIPCHK(c, hipMemcpyAsync(c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+        launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, c->d_active, c->d_models, c->d_valid);
+        launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, c->d_active, h_prev, h_target, thr, c->d_counts);
+        HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(int) * (size_t)F * MAX_HYP, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_valid, c->d_valid, sizeof(int) * (size_t)F * MAX_HYP, hipMemcpyDeviceToHost, c->stream));
+        int st = sync_fs(c, F);   // sync #2 (per round): counts + n_hyp
+        if (st) return st;
+        ++rounds;
+        bool all_done = true;
+        for (int f = 0; f < F; ++f) {
+            if (!c->h_active[f]) continue;
+            const FrameState& s = c->h_fs[f];
+            const bool fin = rep[f].consume(c->h_counts + (size_t)f * MAX_HYP, c->h_valid + (size_t)f * MAX_HYP, s.n_hyp, std::max(1, s.n_v),
+                                            p->plane_max_iterations, p->plane_probability, s.sampler_exhausted != 0 || h_target >= h_cap);
+            if (fin) c->h_active[f] = 0; else all_done = false;
+        }
+        h_prev = h_target;
+        if (all_done) break;
+    }
+    if (rounds_out) *rounds_out = rounds;
+    // chosen models -> device; moments of their inliers -> host eigen33 -> refined models
+    for (int f = 0; f < F; ++f) {
+        iterations[f] = rep[f].iterations;
+        c->h_have[f] = rep[f].best_h >= 0 ? 1 : 0;
+        c->h_model[f] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c->h_have[f])
+            HIPCHK(c, hipMemcpyAsync(&c->h_model[f], c->d_models + (size_t)f * MAX_HYP + rep[f].best_h, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_have, c->h_have, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+    if (p->plane_optimize) {
+        HIPCHK(c, hipMemsetAsync(c->d_sums, 0, sizeof(unsigned long long) * 10 * F, c->stream));
+        launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums);
+        HIPCHK(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(unsigned long long) * 10 * F, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // sync #3
+        for (int f = 0; f < F; ++f) {
+            if (!c->h_have[f]) continue;
+            float in[4] = {c->h_model[f].x, c->h_model[f].y, c->h_model[f].z, c->h_model[f].w}, out[4];
+            hm::plane_refit_from_moments((const uint64_t*)(c->h_sums + 10 * (size_t)f), in, out);
+            c->h_model[f] = make_float4(out[0], out[1], out[2], out[3]);
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
+    }
+    (void)T;
+    return CD_OK;
+}
+
+// S3 (+S3b).  out: d_plane_idx, d_obj, fs.n_plane, fs.n_o
+int stage_extract(cd_context* c, int F, const cd_params* p) {
+    const int T = c->T;
+    const float thr = hm::fold_ge(p->plane_distance_threshold);
+    int max_nv = 0;
+    for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
+    const int Tv = std::max(1, (max_nv + TILE - 1) / TILE);
+    const float z2lo = hm::fold_ge(p->crop2_z_min), z2hi = hm::fold_le(p->crop2_z_max);
+    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_tileB, 0, sizeof(int) * (size_t)F * T, c->stream));
+    launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, c->d_tileA, c->d_tileB);
+    launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_plane), FS_PITCH);
+    launch_scan_tiles(c->stream, c->d_tileB, F, T, FS_FIELD(c, n_o), FS_PITCH);
+    launch_extract_scatter(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, c->d_tileA, c->d_tileB, c->d_plane_idx, c->d_obj);
+    return CD_OK;
+}
+
+// S5.  in: d_obj + fs.n_o (device).  out: d_label, d_sizes, fs.n_k/ksize/koff, d_src0/d_src
+int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint) {
+    const int T = c->T;
+    const int To = std::max(1, (max_no_hint + TILE - 1) / TILE);
+    const float cell = (float)(p->cluster_tolerance * (1.0 + 1.0 / 1024.0));
+    const float inv_cell = 1.0f / cell;
+    const float r2 = (float)(p->cluster_tolerance * p->cluster_tolerance);
+    if (p->cluster_enable) {
+        HIPCHK(c, hipMemsetAsync(c->d_head, 0xff, sizeof(int) * (size_t)F * CELL_BUCKETS, c->stream));
+        launch_cluster_build(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, c->d_head, c->d_next, c->d_parent, c->d_csize, c->d_rank);
+        launch_cluster_hook(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, r2, c->d_head, c->d_next, c->d_parent);
+        launch_cluster_flatten(c->stream, c->N, F, To, c->d_fs, c->d_parent, c->d_csize);
+    }
+    launch_cluster_rank(c->stream, c->N, F, c->d_fs, p->cluster_enable, p->cluster_min_size, p->cluster_max_size, c->d_parent, c->d_csize, c->d_cand, c->d_rank, c->d_sizes);
+    HIPCHK(c, hipMemsetAsync(c->d_tileK, 0, sizeof(int) * (size_t)F * KICP * T, c->stream));
+    launch_label_count(c->stream, c->N, F, T, To, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK);
+    launch_scan_tiles(c->stream, c->d_tileK, F * KICP, T, nullptr, 0);
+    launch_label_scatter(c->stream, c->d_obj, c->N, F, T, To, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src);
+    return CD_OK;
+}
+
+// S6.  clusters described by h_cl[0..ncl) (src_off relative to d_src/d_src0).  Fills h_st / h_accf.
+int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests) {
+    c->timing.icp_kernel_launches = 0;
+    c->timing.icp_kernel_ms = 0.f;
+    if (pair_tests) *pair_tests = 0;
+    if (ncl <= 0) return CD_OK;
+    int nwork = 0;
+    for (int k = 0; k < ncl; ++k) {
+        IcpCluster& cl = c->h_cl[k];
+        cl.tile0 = nwork;
+        const int tiles = cl.n >= 3 && cl.tpl_m > 0 ? (cl.n + BLOCK - 1) / BLOCK : 0;
+        if (nwork + tiles > c->work_cap) return fail(c, CD_ERR_CAPACITY, "ICP work list overflow");
+        for (int t = 0; t < tiles; ++t) c->h_work[nwork++] = IcpWork{k, t};
+        for (int s = 0; s < 2; ++s) {
+            IcpState& st = c->h_st[2 * k + s];
+            std::memset(&st, 0, sizeof(st));
+            for (int i = 0; i < 4; ++i) st.Tfinal[5 * i] = 1.f;
+            st.prev_mse = std::numeric_limits<double>::max();
+            if (cl.tpl_m <= 0) { st.done = 1; st.status = CD_ERR_NO_TEMPLATE; }
+            else if (cl.n < 3) { st.done = 1; st.status = CD_ERR_FEW_CORRESPONDENCES; }
+        }
+    }
+    HIPCHK(c, hipMemcpyAsync(c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
+    IcpParams ip;
+    ip.max_iter = p->icp_max_iterations;
+    ip.pad = 0;
+    ip.trans_eps = p->icp_transformation_epsilon;
+    ip.rel_mse = p->icp_euclidean_fitness_epsilon;
+    ip.rot_thr = 1.0 - p->icp_transformation_epsilon;
+    ip.abs_mse = 1e-12;
+    HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    int it = 0;
+    const int max_launch = p->icp_max_iterations + 3;
+    int group = 16;
+    while (nwork > 0 && it < max_launch) {
+        const int g = std::min(group, max_launch - it);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_src, ip);
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        bool all = true;
+        for (int k = 0; k < ncl && all; ++k) all = c->h_st[2 * k].done && c->h_st[2 * k + 1].done;
+        if (all) break;
+    }
+    HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+    c->timing.icp_kernel_launches = it;
+    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_src0);
+    HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
+    c->timing.icp_kernel_ms = ms;
+    if (pair_tests) {
+        long long tot = 0;
+        for (int k = 0; k < ncl; ++k)
+            if (c->h_st[2 * k].status == CD_OK) tot += (long long)c->h_cl[k].n * c->h_cl[k].tpl_m * (c->h_st[2 * k].iters + 1);
+        *pair_tests = tot;
+    }
+    return CD_OK;
+}
+
+void fill_cluster_result(const cd_context* c, int k, const cd_params* p, cd_cluster_result* r) {
+    const IcpState& st = c->h_st[2 * k];
+    const IcpCluster& cl = c->h_cl[k];
+    std::memset(r, 0, sizeof(*r));
+    r->size = cl.n;
+    r->iterations = st.iters;
+    r->converged = st.converged;
+    std::memcpy(r->T, st.Tfinal, 64);
+    r->fitness = st.status == CD_OK ? hm::unfix(c->h_accf[k], FIX_SHIFT_D2) / (double)cl.n : std::numeric_limits<double>::max();
+    r->accepted = (r->converged && r->fitness < p->icp_accept_fitness) ? 1 : 0;
+    double Td[16];
+    for (int i = 0; i < 16; ++i) Td[i] = (double)st.Tfinal[i];
+    if (!hm::mat4_inverse(Td, r->pose))
+        for (int i = 0; i < 16; ++i) r->pose[i] = std::numeric_limits<double>::quiet_NaN();
+}
+
+int upload_points(cd_context* c, const void* pts, size_t stride, int n, float4* dst) {
+    // host (stride) -> device float4 via the staging buffer
+    if (n <= 0) return CD_OK;
+    std::vector<float4> tmp((size_t)n);
+    const char* b = (const char*)pts;
+    for (int i = 0; i < n; ++i) {
+        float v[3];
+        std::memcpy(v, b + (size_t)i * stride, 12);
+        tmp[i] = make_float4(v[0], v[1], v[2], 0.f);
+    }
+    HIPCHK(c, hipMemcpyAsync(dst, tmp.data(), sizeof(float4) * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return CD_OK;
+}
+
+int check_params(cd_context* c, const cd_params* p) {
+    if (!p) return fail(c, CD_ERR_INVALID_ARG, "params is NULL");
+    if (!(p->leaf_size > 0.f)) return fail(c, CD_ERR_INVALID_ARG, "leaf_size must be > 0");
+    if (p->plane_max_iterations < 0 || p->plane_max_iterations > 1000) return fail(c, CD_ERR_INVALID_ARG, "plane_max_iterations must be in [0,1000]");
+    if (p->template_slot < 0 || p->template_slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "template_slot out of range");
+    if (!(p->cluster_tolerance > 0.0)) return fail(c, CD_ERR_INVALID_ARG, "cluster_tolerance must be > 0");
+    return CD_OK;
+}
+
+int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N, int F, const cd_params* p,
+                       cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
+    int st = check_params(c, p);
+    if (st) return st;
+    if (!results || !d_frames) return fail(c, CD_ERR_INVALID_ARG, "null pointer");
+    if (N <= 0 || F <= 0 || stride < 12 || (stride & 3)) return fail(c, CD_ERR_INVALID_ARG, "bad shape/stride");
+    if (N > c->N || F > c->F) return fail(c, CD_ERR_CAPACITY, "batch larger than the context capacity");
+    std::memset(&c->timing, 0, sizeof(c->timing));
+    HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    int rounds = 0;
+    st = stage_crop_voxel(c, d_frames, stride, N, F, p, nullptr);
+    if (st) return st;
+    st = sync_fs(c, F);   // n_v
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev[1], c->stream));
+    std::vector<int> iterations;
+    st = stage_plane(c, F, p, iterations, &rounds);
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
+    st = stage_extract(c, F, p);
+    if (st) return st;
+    int max_nv = 0;
+    for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
+    st = stage_cluster(c, F, p, max_nv);
+    if (st) return st;
+    st = sync_fs(c, F);   // sync #4: n_plane, n_o, n_k, ksize, koff
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    // ICP problems
+    const int slot = p->template_slot;
+    int ncl = 0;
+    std::vector<int> first_cl(F, 0);
+    for (int f = 0; f < F; ++f) {
+        first_cl[f] = ncl;
+        const FrameState& s = c->h_fs[f];
+        const int kk = std::min(s.n_k, KICP);
+        for (int k = 0; k < kk; ++k) {
+            IcpCluster& cl = c->h_cl[ncl++];
+            cl.src_off = f * c->N + s.koff[k];
+            cl.n = s.ksize[k];
+            cl.frame = f;
+            cl.k = k;
+            cl.tpl_off = c->tpl_off[slot];
+            cl.tpl_m = c->tpl_m[slot];
+            cl.tile0 = 0;
+            cl.pad = 0;
+        }
+    }
+    long long pairs = 0;
+    st = stage_icp(c, ncl, p, &pairs);
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
+    // records
+    long long balg = 0;
+    for (int f = 0; f < F; ++f) {
+        const FrameState& s = c->h_fs[f];
+        cd_frame_result& r = results[f];
+        std::memset(&r, 0, sizeof(r));
+        r.status = s.status;
+        r.n_cropped = s.n_cropped;
+        r.n_voxels = s.n_v;
+        r.n_plane = s.n_plane;
+        r.n_objects = s.n_o;
+        r.n_clusters = s.n_k;
+        r.ransac_iterations = iterations[f];
+        if (s.status == CD_OK && !c->h_have[f]) r.status = CD_ERR_NO_MODEL;
+        if (c->h_have[f]) { r.plane[0] = c->h_model[f].x; r.plane[1] = c->h_model[f].y; r.plane[2] = c->h_model[f].z; r.plane[3] = c->h_model[f].w; }
+        const int kk = std::min(s.n_k, KICP);
+        balg += 12ll * N + 12ll * s.n_v + 12ll * s.n_v * (rounds + 3) + 4ll * s.n_v + 16ll * s.n_o + 200ll * s.n_k;
+        for (int k = 0; k < kk; ++k) {
+            fill_cluster_result(c, first_cl[f] + k, p, &r.clusters[k]);
+            balg += 12ll * c->tpl_m[slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
+        }
+    }
+    if (plane_inliers || labels) {
+        std::vector<int32_t> tmp((size_t)c->N);
+        for (int f = 0; f < F; ++f) {
+            const FrameState& s = c->h_fs[f];
+            if (plane_inliers) {
+                int32_t* dst = plane_inliers + (size_t)f * N;
+                std::fill(dst, dst + N, -1);
+                if (s.n_plane > 0) HIPCHK(c, hipMemcpy(dst, c->d_plane_idx + (size_t)f * c->N, sizeof(int) * s.n_plane, hipMemcpyDeviceToHost));
+            }
+            if (labels) {
+                int32_t* dst = labels + (size_t)f * N;
+                std::fill(dst, dst + N, -1);
+                if (s.n_o > 0) HIPCHK(c, hipMemcpy(dst, c->d_label + (size_t)f * c->N, sizeof(int) * s.n_o, hipMemcpyDeviceToHost));
+            }
+        }
+    }
+    HIPCHK(c, hipEventSynchronize(c->ev[4]));
+    for (int k = 0; k < 4; ++k) hipEventElapsedTime(&c->timing.stage_ms[k], c->ev[k], c->ev[k + 1]);
+    hipEventElapsedTime(&c->timing.stage_ms[4], c->ev[0], c->ev[4]);
+    c->timing.icp_pair_tests_lo = (int32_t)(pairs & 0xffffffffll);
+    c->timing.icp_pair_tests_hi = (int32_t)(pairs >> 32);
+    c->timing.algorithmic_bytes = balg;
+    return CD_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+extern "C" {
+
+void cd_default_params(cd_params* p) {
+    if (!p) return;
+    std::memset(p, 0, sizeof(*p));
+    p->crop_z_min = 0.0; p->crop_z_max = 0.9;            // gps.cpp:56
+    p->crop_x_min = -0.2; p->crop_x_max = 0.2;           // gps.cpp:64
+    p->leaf_size = 0.005f;                               // ground_plane_segmentation.launch:16
+    p->rgb_offset = -1;
+    p->plane_distance_threshold = 0.015;                 // ground_plane_segmentation.launch:18
+    p->plane_max_iterations = 1000;                      // gps.cpp:88
+    p->plane_optimize = 1;                               // gps.cpp:85
+    p->plane_probability = 0.99;                         // PCL default
+    p->extract_negative = 1;                             // launch: invert: true
+    p->crop2_enable = 1; p->crop2_z_min = 0.0; p->crop2_z_max = 0.75;   // opd.cpp:335
+    p->cluster_enable = 1;
+    p->cluster_min_size = 200; p->cluster_max_size = 25000;             // opd.cpp:357-358
+    p->cluster_tolerance = 0.02;                         // opd.cpp:356
+    p->icp_max_iterations = 5000;                        // icp.cpp:173
+    p->template_slot = 0;
+    p->icp_transformation_epsilon = 1e-9;                // icp.cpp:174
+    p->icp_euclidean_fitness_epsilon = 0.0004;           // icp.cpp:176 + launch:42
+    p->icp_accept_fitness = 0.0004;                      // icp.cpp:182
+}
+
+int cd_abi_version(void) { return CD_ABI_VERSION; }
+
+int cd_struct_size(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(cd_params);
+        case 1: return (int)sizeof(cd_cluster_result);
+        case 2: return (int)sizeof(cd_frame_result);
+        case 3: return (int)sizeof(cd_timing);
+        default: return -1;
+    }
+}
+
+const char* cd_last_error(const cd_context* ctx) { return ctx ? ctx->err : "null context"; }
+
+void cd_destroy(cd_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
+                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
+                   c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
+    for (void* p : dev) if (p) hipFree(p);
+    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
+    for (void* p : host) if (p) hipHostFree(p);
+    for (auto& e : c->ev) if (e) hipEventDestroy(e);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
+    if (!out) return CD_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (max_points <= 0 || max_frames <= 0) return CD_ERR_INVALID_ARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device_id < 0 || device_id >= ndev) return CD_ERR_DEVICE;
+    if (hipSetDevice(device_id) != hipSuccess) return CD_ERR_DEVICE;
+    cd_context* c = new cd_context();
+    c->device = device_id;
+    c->N = max_points;
+    c->F = max_frames;
+    c->T = (max_points + TILE - 1) / TILE;
+    const size_t N = (size_t)c->N, F = (size_t)c->F, T = (size_t)c->T, FN = F * N;
+    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && dalloc(&c->d_fs, F) == hipSuccess && halloc(&c->h_fs, F) == hipSuccess;
+    ok = ok && dalloc(&c->d_tileA, F * T) == hipSuccess && dalloc(&c->d_tileB, F * T) == hipSuccess && dalloc(&c->d_tileK, F * KICP * T) == hipSuccess;
+    ok = ok && dalloc(&c->d_cpt, FN) == hipSuccess && dalloc(&c->d_vox, FN) == hipSuccess && dalloc(&c->d_obj, FN) == hipSuccess;
+    ok = ok && dalloc(&c->d_src0, FN) == hipSuccess && dalloc(&c->d_src, FN) == hipSuccess;
+    for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
+    ok = ok && dalloc(&c->d_hist, F * RADIX * T) == hipSuccess;
+    ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
+    ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
+    ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess;
+    ok = ok && dalloc(&c->d_active, F) == hipSuccess && halloc(&c->h_active, F) == hipSuccess;
+    ok = ok && dalloc(&c->d_model, F) == hipSuccess && halloc(&c->h_model, F) == hipSuccess;
+    ok = ok && dalloc(&c->d_have, F) == hipSuccess && halloc(&c->h_have, F) == hipSuccess;
+    ok = ok && dalloc(&c->d_sums, F * 10) == hipSuccess && halloc(&c->h_sums, F * 10) == hipSuccess;
+    ok = ok && dalloc(&c->d_plane_idx, FN) == hipSuccess && dalloc(&c->d_head, F * CELL_BUCKETS) == hipSuccess;
+    ok = ok && dalloc(&c->d_next, FN) == hipSuccess && dalloc(&c->d_parent, FN) == hipSuccess && dalloc(&c->d_csize, FN) == hipSuccess;
+    ok = ok && dalloc(&c->d_rank, FN) == hipSuccess && dalloc(&c->d_cand, FN) == hipSuccess && dalloc(&c->d_sizes, FN) == hipSuccess && dalloc(&c->d_label, FN) == hipSuccess;
+    c->tpl_cap = 1 << 18;
+    ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
+    const size_t ncl = F * KICP;
+    c->work_cap = (int)(F * (N / BLOCK + KICP + 1));
+    ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
+    ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
+    ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;
+    ok = ok && dalloc(&c->d_acc, ncl * 48) == hipSuccess && dalloc(&c->d_accf, ncl) == hipSuccess && halloc(&c->h_accf, ncl) == hipSuccess;
+    if (ok) {
+        // PCL's SAC sampler: boost::mt19937 seeded 12345, uniform_int<>(0, INT_MAX) == mt() >> 1
+        std::vector<int> tab((size_t)RND_TABLE);
+        std::mt19937 gen(12345u);
+        for (auto& v : tab) v = (int)(gen() >> 1);
+        ok = hipMemcpy(c->d_rnd, tab.data(), sizeof(int) * RND_TABLE, hipMemcpyHostToDevice) == hipSuccess;
+    }
+    if (!ok) {
+        cd_destroy(c);
+        return CD_ERR_DEVICE;
+    }
+    *out = c;
+    return CD_OK;
+}
+
+int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int m) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= CD_MAX_TEMPLATES || !xyz || m <= 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad template arguments");
+    hipSetDevice(c->device);
+    // templates are appended; re-setting a slot with a template that fits reuses its space
+    int off;
+    if (c->tpl_m[slot] >= m) off = c->tpl_off[slot];
+    else {
+        if (c->tpl_used + m > c->tpl_cap) return fail(c, CD_ERR_CAPACITY, "template storage exhausted");
+        off = c->tpl_used;
+        c->tpl_used += m;
+    }
+    int st = upload_points(c, xyz, stride, m, c->d_tpl + off);
+    if (st) return st;
+    c->tpl_off[slot] = off;
+    c->tpl_m[slot] = m;
+    return CD_OK;
+}
+
+int cd_crop_voxel(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float* out_xyz,
+                  uint32_t* out_rgb, int capacity, int* out_n_cropped, int* out_n_voxels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    int st = check_params(c, p);
+    if (st) return st;
+    if (!points || !out_xyz || n < 0 || stride < 12 || (stride & 3)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    if (n > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    if (out_n_cropped) *out_n_cropped = 0;
+    if (out_n_voxels) *out_n_voxels = 0;
+    if (n == 0) return CD_OK;
+    st = ensure_input(c, (size_t)n * stride);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, points, (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
+    st = stage_crop_voxel(c, c->d_in, stride, n, 1, p, nullptr);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    const FrameState& s = c->h_fs[0];
+    if (out_n_cropped) *out_n_cropped = s.n_cropped;
+    if (s.status != CD_OK) return fail(c, s.status, "voxel grid: leaf size too small for the input extent");
+    if (s.n_v > capacity) return fail(c, CD_ERR_CAPACITY, "output capacity too small");
+    std::vector<float4> tmp((size_t)std::max(s.n_v, 1));
+    HIPCHK(c, hipMemcpy(tmp.data(), c->d_vox, sizeof(float4) * s.n_v, hipMemcpyDeviceToHost));
+    for (int i = 0; i < s.n_v; ++i) {
+        out_xyz[3 * i] = tmp[i].x; out_xyz[3 * i + 1] = tmp[i].y; out_xyz[3 * i + 2] = tmp[i].z;
+        if (out_rgb) std::memcpy(&out_rgb[i], &tmp[i].w, 4);
+    }
+    if (out_n_voxels) *out_n_voxels = s.n_v;
+    return CD_OK;
+}
+
+// helper: load a caller cloud as the (single-frame) voxel cloud / object cloud
+static int load_as(cd_context* c, const void* xyz, size_t stride, int n, float4* dst, int32_t FrameState::*count) {
+    if (n > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    int st = upload_points(c, xyz, stride, n, dst);
+    if (st) return st;
+    std::memset(&c->h_fs[0], 0, sizeof(FrameState));
+    c->h_fs[0].*count = n;
+    // origin for the cluster hash: min of the cloud
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    const char* b = (const char*)xyz;
+    for (int i = 0; i < n; ++i) {
+        float v[3];
+        std::memcpy(v, b + (size_t)i * stride, 12);
+        for (int a = 0; a < 3; ++a) if (v[a] < mn[a]) mn[a] = v[a];
+    }
+    for (int a = 0; a < 3; ++a) c->h_fs[0].origin[a] = n > 0 ? mn[a] : 0.f;
+    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+    return CD_OK;
+}
+
+int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, float coeff[4],
+                     int32_t* inliers, int capacity, int* out_n_inliers, int* out_iterations) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    int st = check_params(c, p);
+    if (st) return st;
+    if (!xyz || !coeff || !inliers || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    if (out_n_inliers) *out_n_inliers = 0;
+    if (out_iterations) *out_iterations = 0;
+    st = load_as(c, xyz, stride, n, c->d_vox, &FrameState::n_v);
+    if (st) return st;
+    std::vector<int> iters;
+    st = stage_plane(c, 1, p, iters, nullptr);
+    if (st) return st;
+    if (out_iterations) *out_iterations = iters[0];
+    if (!c->h_have[0]) return CD_ERR_NO_MODEL;
+    cd_params q = *p;
+    q.extract_negative = 1;
+    q.crop2_enable = 0;
+    st = stage_extract(c, 1, &q);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    const int ni = c->h_fs[0].n_plane;
+    if (ni > capacity) return fail(c, CD_ERR_CAPACITY, "inlier capacity too small");
+    if (ni > 0) HIPCHK(c, hipMemcpy(inliers, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    coeff[0] = c->h_model[0].x; coeff[1] = c->h_model[0].y; coeff[2] = c->h_model[0].z; coeff[3] = c->h_model[0].w;
+    if (out_n_inliers) *out_n_inliers = ni;
+    return CD_OK;
+}
+
+int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels,
+               int32_t* sizes, int sizes_capacity, int* out_k) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    int st = check_params(c, p);
+    if (st) return st;
+    if (!xyz || !labels || n < 0 || stride < 12 || (sizes_capacity > 0 && !sizes)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    if (out_k) *out_k = 0;
+    if (n == 0) return CD_OK;
+    st = load_as(c, xyz, stride, n, c->d_obj, &FrameState::n_o);
+    if (st) return st;
+    st = stage_cluster(c, 1, p, n);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    HIPCHK(c, hipMemcpy(labels, c->d_label, sizeof(int) * n, hipMemcpyDeviceToHost));
+    const int K = c->h_fs[0].n_k;
+    const int ks = std::min(K, sizes_capacity);
+    if (ks > 0) HIPCHK(c, hipMemcpy(sizes, c->d_sizes, sizeof(int) * ks, hipMemcpyDeviceToHost));
+    if (out_k) *out_k = K;
+    return CD_OK;
+}
+
+int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, const cd_params* p,
+           cd_cluster_result* out, float* aligned) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    int st = check_params(c, p);
+    if (st) return st;
+    if (!src_xyz || !out || n < 0 || stride < 12 || slot < 0 || slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    if (n > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    if (c->tpl_m[slot] <= 0) return fail(c, CD_ERR_NO_TEMPLATE, "template slot is empty");
+    st = upload_points(c, src_xyz, stride, n, c->d_src0);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_src, c->d_src0, sizeof(float4) * (size_t)std::max(n, 1), hipMemcpyDeviceToDevice, c->stream));
+    IcpCluster& cl = c->h_cl[0];
+    cl.src_off = 0; cl.n = n; cl.frame = 0; cl.k = 0; cl.tpl_off = c->tpl_off[slot]; cl.tpl_m = c->tpl_m[slot]; cl.tile0 = 0; cl.pad = 0;
+    st = stage_icp(c, 1, p, nullptr);
+    if (st) return st;
+    fill_cluster_result(c, 0, p, out);
+    if (aligned && n > 0) {
+        std::vector<float4> tmp((size_t)n);
+        HIPCHK(c, hipMemcpy(tmp.data(), c->d_src, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i) { aligned[3 * i] = tmp[i].x; aligned[3 * i + 1] = tmp[i].y; aligned[3 * i + 2] = tmp[i].z; }
+    }
+    return c->h_st[0].status;
+}
+
+int cd_process_batch_device(cd_context* c, const void* d_frames, size_t stride, int points_per_frame, int n_frames,
+                            const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    return process_batch_impl(c, d_frames, stride, points_per_frame, n_frames, p, results, plane_inliers, labels);
+}
+
+int cd_process_batch(cd_context* c, const void* frames, size_t stride, int points_per_frame, int n_frames,
+                     const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if (!frames || points_per_frame <= 0 || n_frames <= 0) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    const size_t bytes = (size_t)points_per_frame * n_frames * stride;
+    int st = ensure_input(c, bytes);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, frames, bytes, hipMemcpyHostToDevice, c->stream));
+    return process_batch_impl(c, c->d_in, stride, points_per_frame, n_frames, p, results, plane_inliers, labels);
+}
+
+int cd_get_timing(const cd_context* c, cd_timing* out) {
+    if (!c || !out) return CD_ERR_INVALID_ARG;
+    *out = c->timing;
+    return CD_OK;
+}
+
+void cd_pose_to_position_quaternion(const double H[16], double pos[3], double q[4]) {
+    pos[0] = H[3]; pos[1] = H[7]; pos[2] = H[11];
+    const double m[3][3] = {{H[0], H[1], H[2]}, {H[4], H[5], H[6]}, {H[8], H[9], H[10]}};
+    const double trace = m[0][0] + m[1][1] + m[2][2];
+    double t[4];
+    if (trace > 0.0) {
+        double s = std::sqrt(trace + 1.0);
+        t[3] = s * 0.5;
+        s = 0.5 / s;
+        t[0] = (m[2][1] - m[1][2]) * s;
+        t[1] = (m[0][2] - m[2][0]) * s;
+        t[2] = (m[1][0] - m[0][1]) * s;
+    } else {
+        const int i = m[0][0] < m[1][1] ? (m[1][1] < m[2][2] ? 2 : 1) : (m[0][0] < m[2][2] ? 2 : 0);
+        const int j = (i + 1) % 3, k = (i + 2) % 3;
+        double s = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        t[i] = s * 0.5;
+        s = 0.5 / s;
+        t[3] = (m[k][j] - m[j][k]) * s;
+        t[j] = (m[j][i] + m[i][j]) * s;
+        t[k] = (m[k][i] + m[i][k]) * s;
+    }
+    q[0] = t[0]; q[1] = t[1]; q[2] = t[2]; q[3] = t[3];
+}
+
+void cd_bbox_corners(const double H[16], double l, double w, double h, float out[24]) {
+    float Hf[16];
+    for (int i = 0; i < 16; ++i) Hf[i] = (float)H[i];
+    const double sx[8] = {-1, -1, -1, -1, 1, 1, 1, 1}, sy[8] = {-1, -1, 1, 1, -1, -1, 1, 1}, sz[8] = {-1, 1, -1, 1, -1, 1, -1, 1};
+    for (int k = 0; k < 8; ++k) {
+        const float x = (float)(sx[k] * l / 2), y = (float)(sy[k] * w / 2), z = (float)(sz[k] * h / 2);
+        out[3 * k] = ((Hf[0] * x + Hf[1] * y) + Hf[2] * z) + Hf[3];
+        out[3 * k + 1] = ((Hf[4] * x + Hf[5] * y) + Hf[6] * z) + Hf[7];
+        out[3 * k + 2] = ((Hf[8] * x + Hf[9] * y) + Hf[10] * z) + Hf[11];
+    }
+}
+
+}  // extern "C"

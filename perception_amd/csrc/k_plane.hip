@@ -1,0 +1,279 @@
+// k_plane.hip - S2 RANSAC plane segmentation + S3 extract (+S3b second z crop).
+//
+// Replaces pcl::SACSegmentation<PointXYZ>::segment (SACMODEL_PLANE, SAC_RANSAC, optimize) and
+// pcl::ExtractIndices / pcl::PassThrough that follow it (reference:
+// cuboid_detection/src/ground_plane_segmentation.cpp:76-101,
+// object_detection/src/object_pose_detection.cpp:300-336).
+//
+// PCL re-seeds its sampler with 12345 for every frame, so the hypothesis sequence is a pure
+// function of the voxel cloud: k_ransac_sample replays PCL's drawIndexSample / isSampleGood /
+// computeModelCoefficients serially (one lane per frame, shuffle state in an LDS hash map) and
+// emits the first h_target plane models; k_ransac_count then scores ALL of them in ONE pass
+// over the cloud: each lane keeps 8 points in registers (coalesced 16 B loads), the plane
+// coefficients are wave-uniform (scalar loads), the inlier test is reduced per hypothesis with
+// a 64-wide ballot + popcount and one atomic per wave.  The host replays PCL's sequential
+// adaptive-k stop rule over the count vector (bit-exact: counts are integers).
+#include "kernels.hpp"
+
+namespace cd {
+
+// ---- sampler: PCL SampleConsensusModel::getSamples + plane model -------------------------
+__global__ void __launch_bounds__(WAVE) k_ransac_sample(const float4* __restrict__ vox, int N,
+                                                        FrameState* __restrict__ fs, const int* __restrict__ rnd,
+                                                        int h_target, const int* __restrict__ active,
+                                                        float4* __restrict__ models, int* __restrict__ valid) {
+    __shared__ int s_key[SAMPLER_MAP];
+    __shared__ int s_val[SAMPLER_MAP];
+    const int f = blockIdx.x;
+    if (active && !active[f]) return;
+    for (int i = threadIdx.x; i < SAMPLER_MAP; i += WAVE) s_key[i] = -1;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    const int n = fs[f].n_v;
+    const float4* P = vox + (size_t)f * N;
+    float4* M = models + (size_t)f * MAX_HYP;
+    int* V = valid + (size_t)f * MAX_HYP;
+    if (n < 3) { fs[f].n_hyp = 0; fs[f].sampler_exhausted = 1; return; }
+    auto slot = [&](int pos) {
+        uint32_t h = ((uint32_t)pos * 2654435761u) & (SAMPLER_MAP - 1);
+        while (s_key[h] != -1 && s_key[h] != pos) h = (h + 1) & (SAMPLER_MAP - 1);
+        return (int)h;
+    };
+    int rp = 0, h = 0, used = 0, exhausted = 0;
+    auto get = [&](int pos) { const int h = slot(pos); return s_key[h] == pos ? s_val[h] : pos; };
+    auto set = [&](int pos, int v) { const int h = slot(pos); if (s_key[h] == -1) ++used; s_key[h] = pos; s_val[h] = v; };
+    while (h < h_target) {
+        bool good = false;
+        int s0 = 0, s1 = 0, s2 = 0;
+        for (int it = 0; it < 1000; ++it) {            // max_sample_checks_
+            if (rp + 3 > RND_TABLE || used + 6 > (SAMPLER_MAP * 3) / 4) { exhausted = 1; break; }
+            for (int i = 0; i < 3; ++i) {               // drawIndexSample
+                const uint32_t r = (uint32_t)rnd[rp++];
+                const int j = i + (int)(r % (uint32_t)(n - i));
+                const int vi = get(i), vj = get(j);
+                set(i, vj); set(j, vi);
+            }
+            s0 = get(0); s1 = get(1); s2 = get(2);
+            const float4 p0 = P[s0], p1 = P[s1], p2 = P[s2];
+            // isSampleGood: (p1-p0)/(p2-p0) component ratios not all equal
+            const float q0 = __fdiv_rn(p1.x - p0.x, p2.x - p0.x);
+            const float q1 = __fdiv_rn(p1.y - p0.y, p2.y - p0.y);
+            const float q2 = __fdiv_rn(p1.z - p0.z, p2.z - p0.z);
+            if ((q0 != q1) || (q2 != q1)) { good = true; break; }
+        }
+        if (!good) { exhausted = 1; break; }
+        // computeModelCoefficients
+        const float4 p0 = P[s0], p1 = P[s1], p2 = P[s2];
+        const float ax = p1.x - p0.x, ay = p1.y - p0.y, az = p1.z - p0.z;
+        const float bx = p2.x - p0.x, by = p2.y - p0.y, bz = p2.z - p0.z;
+        const float q0 = __fdiv_rn(ax, bx), q1 = __fdiv_rn(ay, by), q2 = __fdiv_rn(az, bz);
+        int ok = 1;
+        float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (q0 == q1 && q2 == q1) {
+            ok = 0;   // collinear: PCL skips the hypothesis (++skipped_count)
+        } else {
+            float mx = __fsub_rn(__fmul_rn(ay, bz), __fmul_rn(az, by));
+            float my = __fsub_rn(__fmul_rn(az, bx), __fmul_rn(ax, bz));
+            float mz = __fsub_rn(__fmul_rn(ax, by), __fmul_rn(ay, bx));
+            const float nrm = __fsqrt_rn(__fadd_rn(__fadd_rn(__fmul_rn(mx, mx), __fmul_rn(my, my)), __fmul_rn(mz, mz)));
+            mx = __fdiv_rn(mx, nrm); my = __fdiv_rn(my, nrm); mz = __fdiv_rn(mz, nrm);
+            const float d = __fmul_rn(-1.0f, __fadd_rn(__fadd_rn(__fmul_rn(mx, p0.x), __fmul_rn(my, p0.y)), __fmul_rn(mz, p0.z)));
+            m = make_float4(mx, my, mz, d);
+        }
+        M[h] = m;
+        V[h] = ok;
+        ++h;
+    }
+    fs[f].n_hyp = h;
+    fs[f].sampler_exhausted = exhausted;
+}
+
+// ---- batched per-hypothesis inlier count --------------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_ransac_count(const float4* __restrict__ vox, int N,
+                                                        const FrameState* __restrict__ fs,
+                                                        const float4* __restrict__ models, const int* __restrict__ valid,
+                                                        const int* __restrict__ active, int h0, int h1, float thr,
+                                                        int* __restrict__ counts) {
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (active && !active[f]) return;
+    const int n = fs[f].n_v;
+    if (tile * TILE >= n) return;
+    const int hmax = min(h1, fs[f].n_hyp);
+    const float4* P = vox + (size_t)f * N;
+    const int base = tile * TILE + w * WAVE_SPAN + lane;
+    float px[ITEMS], py[ITEMS], pz[ITEMS];
+    bool in[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        in[j] = e < n;
+        const float4 p = in[j] ? P[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        px[j] = p.x; py[j] = p.y; pz[j] = p.z;
+    }
+    const float4* M = models + (size_t)f * MAX_HYP;
+    const int* V = valid + (size_t)f * MAX_HYP;
+    for (int h = h0; h < hmax; ++h) {
+        if (!V[h]) continue;
+        const float4 m = M[h];
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j)
+            c += __popcll(__ballot(in[j] && plane_dist(m.x, m.y, m.z, m.w, px[j], py[j], pz[j]) < thr));
+        if (lane == 0 && c) atomicAdd(&counts[(size_t)f * MAX_HYP + h], c);
+    }
+}
+
+__device__ __forceinline__ bool plane_inlier(const float4& m, int have, float thr, const float4& p) {
+    return have && plane_dist(m.x, m.y, m.z, m.w, p.x, p.y, p.z) < thr;
+}
+
+// ---- 9 fixed-point moments of the inliers of the chosen model (rule C4) --------------------
+// computeMeanAndCovarianceMatrix's accumulators: xx xy xz yy yz zz x y z (+ count)
+__global__ void __launch_bounds__(BLOCK) k_plane_cov(const float4* __restrict__ vox, int N,
+                                                     const FrameState* __restrict__ fs, const float4* __restrict__ model,
+                                                     const int* __restrict__ have, float thr,
+                                                     unsigned long long* __restrict__ sums) {
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_v;
+    if (tile * TILE >= n || !have[f]) return;
+    const float4 m = model[f];
+    const float4* P = vox + (size_t)f * N;
+    const int base = tile * TILE + w * WAVE_SPAN + lane;
+    unsigned long long S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        if (e < n) {
+            const float4 p = P[e];
+            if (plane_inlier(m, 1, thr, p)) {
+                S[0] += (unsigned long long)fixq(__fmul_rn(p.x, p.x), FIX_SHIFT);
+                S[1] += (unsigned long long)fixq(__fmul_rn(p.x, p.y), FIX_SHIFT);
+                S[2] += (unsigned long long)fixq(__fmul_rn(p.x, p.z), FIX_SHIFT);
+                S[3] += (unsigned long long)fixq(__fmul_rn(p.y, p.y), FIX_SHIFT);
+                S[4] += (unsigned long long)fixq(__fmul_rn(p.y, p.z), FIX_SHIFT);
+                S[5] += (unsigned long long)fixq(__fmul_rn(p.z, p.z), FIX_SHIFT);
+                S[6] += (unsigned long long)fixq(p.x, FIX_SHIFT);
+                S[7] += (unsigned long long)fixq(p.y, FIX_SHIFT);
+                S[8] += (unsigned long long)fixq(p.z, FIX_SHIFT);
+                S[9] += 1ull;
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k) {
+        const unsigned long long t = wave_sum_u64(S[k]);
+        if (lane == 0 && t) atomicAdd(&sums[(size_t)f * 10 + k], t);
+    }
+}
+
+// ---- S3: flags by the refined model, ordered compaction of (plane inliers) and (objects) ----
+__device__ __forceinline__ void extract_flags(const float4& m, int have, float thr, int negative, int crop2, float z2lo,
+                                              float z2hi, const float4& p, bool& inl, bool& obj) {
+    inl = plane_inlier(m, have, thr, p);
+    obj = negative ? !inl : inl;
+    if (obj && crop2) obj = (p.z >= z2lo) && (p.z <= z2hi);   // voxel centroids are finite
+}
+
+__global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __restrict__ vox, int N, int T,
+                                                            const FrameState* __restrict__ fs,
+                                                            const float4* __restrict__ model, const int* __restrict__ have,
+                                                            float thr, int negative, int crop2, float z2lo, float z2hi,
+                                                            int* __restrict__ cnt_plane, int* __restrict__ cnt_obj) {
+    __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_v;
+    if (tile * TILE >= n) return;
+    const float4 m = model[f];
+    const int hv = have[f];
+    const float4* P = vox + (size_t)f * N;
+    const int base = tile * TILE + w * WAVE_SPAN + lane;
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        bool inl = false, obj = false;
+        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, P[e], inl, obj);
+        ca += __popcll(__ballot(inl));
+        cb += __popcll(__ballot(obj));
+    }
+    if (lane == 0) { s_a[w] = ca; s_b[w] = cb; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cnt_plane[(size_t)f * T + tile] = s_a[0] + s_a[1] + s_a[2] + s_a[3];
+        cnt_obj[(size_t)f * T + tile] = s_b[0] + s_b[1] + s_b[2] + s_b[3];
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_extract_scatter(const float4* __restrict__ vox, int N, int T,
+                                                           const FrameState* __restrict__ fs,
+                                                           const float4* __restrict__ model, const int* __restrict__ have,
+                                                           float thr, int negative, int crop2, float z2lo, float z2hi,
+                                                           const int* __restrict__ off_plane, const int* __restrict__ off_obj,
+                                                           int* __restrict__ plane_idx, float4* __restrict__ obj_out) {
+    __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_v;
+    if (tile * TILE >= n) return;
+    const size_t fbase = (size_t)f * N;
+    const float4 m = model[f];
+    const int hv = have[f];
+    const float4* P = vox + fbase;
+    const int base = tile * TILE + w * WAVE_SPAN + lane;
+    float4 p[ITEMS];
+    uint64_t ba[ITEMS], bb[ITEMS];
+    int ca = 0, cb = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        bool inl = false, obj = false;
+        p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (e < n) {
+            p[j] = P[e];
+            extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, p[j], inl, obj);
+        }
+        ba[j] = __ballot(inl);
+        bb[j] = __ballot(obj);
+        ca += __popcll(ba[j]);
+        cb += __popcll(bb[j]);
+    }
+    if (lane == 0) { s_a[w] = ca; s_b[w] = cb; }
+    __syncthreads();
+    int pa = off_plane[(size_t)f * T + tile], pb = off_obj[(size_t)f * T + tile];
+    for (int q = 0; q < w; ++q) { pa += s_a[q]; pb += s_b[q]; }
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        if ((ba[j] >> lane) & 1ull) plane_idx[fbase + pa + __popcll(ba[j] & lt)] = e;
+        if ((bb[j] >> lane) & 1ull) obj_out[fbase + pb + __popcll(bb[j] & lt)] = p[j];
+        pa += __popcll(ba[j]);
+        pb += __popcll(bb[j]);
+    }
+}
+
+void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,
+                          int h_target, const int* active, float4* models, int* valid) {
+    hipLaunchKernelGGL(k_ransac_sample, dim3(F), dim3(WAVE), 0, s, vox, N, fs, rnd_table, h_target, active, models, valid);
+}
+void launch_ransac_count(hipStream_t s, const float4* vox, int N, int F, int Tact, const FrameState* fs,
+                         const float4* models, const int* valid, const int* active, int h0, int h1, float thr, int* counts) {
+    hipLaunchKernelGGL(k_ransac_count, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, fs, models, valid, active, h0, h1, thr, counts);
+}
+void launch_plane_cov(hipStream_t s, const float4* vox, int N, int F, int Tact, const FrameState* fs, const float4* model,
+                      const int* have, float thr, unsigned long long* sums) {
+    hipLaunchKernelGGL(k_plane_cov, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, fs, model, have, thr, sums);
+}
+void launch_plane_flag_count(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
+                             const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
+                             float z2hi, int* cnt_plane, int* cnt_obj) {
+    hipLaunchKernelGGL(k_plane_flag_count, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, T, fs, model, have, thr, negative,
+                       crop2, z2lo, z2hi, cnt_plane, cnt_obj);
+}
+void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
+                            const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
+                            float z2hi, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj) {
+    hipLaunchKernelGGL(k_extract_scatter, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, T, fs, model, have, thr, negative,
+                       crop2, z2lo, z2hi, off_plane, off_obj, plane_idx, obj);
+}
+
+}  // namespace cd

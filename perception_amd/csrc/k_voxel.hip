@@ -1,0 +1,314 @@
+// k_voxel.hip - S0 crop (two PassThrough filters) + S1 VoxelGrid.
+//
+// Replaces pcl::PassThrough<PCLPointCloud2>::filter x2 and pcl::VoxelGrid<PCLPointCloud2>::filter
+// (reference: cuboid_detection/src/ground_plane_segmentation.cpp:53-73,
+//  object_detection/src/object_pose_detection.cpp:273-298).
+//
+// Data layout: every per-point array is frame-major with pitch N (= points per frame).
+// An "ordered tile" is 2048 consecutive elements; wave w of the 256-thread block owns the
+// contiguous 512-element span [w*512,(w+1)*512) as 8 rows of 64 lanes, so every row is one
+// fully coalesced 1 KiB (16 B/lane) access and element order == (wave, row, lane) order.
+// Order-preserving stream compaction = per-row wave ballot + popcount prefix, one LDS
+// exchange of the 4 wave totals, plus a per-frame exclusive scan of the tile totals.
+#include "kernels.hpp"
+
+namespace cd {
+
+__device__ __forceinline__ void load_point(const char* __restrict__ in, size_t stride, size_t idx, int rgb_off,
+                                           float& x, float& y, float& z, uint32_t& rgb) {
+    const char* p = in + idx * stride;
+    if (stride == 16 && rgb_off == 12) {
+        const float4 v = *reinterpret_cast<const float4*>(p);
+        x = v.x; y = v.y; z = v.z; rgb = __float_as_uint(v.w);
+    } else {
+        x = *reinterpret_cast<const float*>(p);
+        y = *reinterpret_cast<const float*>(p + 4);
+        z = *reinterpret_cast<const float*>(p + 8);
+        rgb = rgb_off >= 0 ? *reinterpret_cast<const uint32_t*>(p + rgb_off) : 0u;
+    }
+}
+
+// PCL keeps a point iff xyz finite and !(v > max) && !(v < min) with v promoted to double;
+// the double limits were folded on the host into the exactly equivalent float limits.
+__device__ __forceinline__ bool crop_keep(float x, float y, float z, const CropLimits& L) {
+    const bool fin = (fabsf(x) <= 3.402823466e38f) && (fabsf(y) <= 3.402823466e38f) && (fabsf(z) <= 3.402823466e38f);
+    return fin && z >= L.zlo && z <= L.zhi && x >= L.xlo && x <= L.xhi;
+}
+
+// ---- pass A: survivors per tile + min/max of the survivors ---------------------------
+__global__ void __launch_bounds__(BLOCK) k_crop_count(const char* __restrict__ in, size_t stride, int N, int rgb_off,
+                                                      CropLimits lim, int T, FrameState* __restrict__ fs,
+                                                      int* __restrict__ tile_cnt) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t fbase = (size_t)f * N;
+    const int base = tile * TILE + w * WAVE_SPAN;
+    int cnt = 0;
+    float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE + lane;
+        bool keep = false;
+        if (e < N) {
+            float x, y, z; uint32_t c;
+            load_point(in, stride, fbase + e, rgb_off, x, y, z, c);
+            keep = crop_keep(x, y, z, lim);
+            if (keep) {
+                mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
+                mx[0] = fmaxf(mx[0], x); mx[1] = fmaxf(mx[1], y); mx[2] = fmaxf(mx[2], z);
+            }
+        }
+        cnt += __popcll(__ballot(keep));
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    }
+    if (lane == 0) {
+        s_cnt[w] = cnt;
+        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k];
+        tile_cnt[(size_t)f * T + tile] = tot;
+        if (tot > 0) {
+            for (int a = 0; a < 3; ++a) {
+                float lo = s_mn[0][a], hi = s_mx[0][a];
+                for (int k = 1; k < WAVES_PER_BLOCK; ++k) { lo = fminf(lo, s_mn[k][a]); hi = fmaxf(hi, s_mx[k][a]); }
+                atomicMin(&fs[f].mn[a], f2ord(lo));
+                atomicMax(&fs[f].mx[a], f2ord(hi));
+            }
+        }
+    }
+}
+
+// ---- per-"row" exclusive scan of tile totals (rows = frames, or frames x bins) --------
+// counts[row*T + t] -> exclusive prefix in place; total -> totals[row*total_pitch].
+__global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, int T, int* __restrict__ totals,
+                                                      int total_pitch) {
+    __shared__ int s_w[WAVES_PER_BLOCK];
+    __shared__ int s_base;
+    const int row = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int* c = counts + (size_t)row * T;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int t0 = 0; t0 < T; t0 += BLOCK) {
+        const int t = t0 + threadIdx.x;
+        const int v = t < T ? c[t] : 0;
+        int inc = v;  // inclusive wave scan
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int wb = 0;
+        for (int k = 0; k < w; ++k) wb += s_w[k];
+        const int base = s_base;
+        if (t < T) c[t] = base + wb + inc - v;
+        __syncthreads();
+        if (threadIdx.x == BLOCK - 1) s_base = base + wb + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && totals) totals[(size_t)row * total_pitch] = s_base;
+}
+
+// ---- voxel grid geometry from the min/max (VoxelGrid::applyFilter prologue) ------------
+__global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= F) return;
+    FrameState& s = fs[f];
+    s.key_bits = 0;
+    s.n_cropped = s.n_c;
+    s.origin[0] = s.origin[1] = s.origin[2] = 0.f;
+    for (int a = 0; a < 3; ++a) { s.min_b[a] = 0; s.div_b[a] = 0; }
+    if (s.n_c <= 0) return;
+    const float inv = __fdiv_rn(1.0f, leaf);
+    float mn[3], mx[3];
+    for (int a = 0; a < 3; ++a) { mn[a] = ord2f(s.mn[a]); mx[a] = ord2f(s.mx[a]); s.origin[a] = mn[a]; }
+    // "Leaf size is too small for the input dataset. Integer indices would overflow."
+    const long long dx = (long long)__fmul_rn(__fsub_rn(mx[0], mn[0]), inv) + 1;
+    const long long dy = (long long)__fmul_rn(__fsub_rn(mx[1], mn[1]), inv) + 1;
+    const long long dz = (long long)__fmul_rn(__fsub_rn(mx[2], mn[2]), inv) + 1;
+    long long cells = 1;
+    bool bad = (dx * dy * dz) > 2147483647ll;
+    for (int a = 0; a < 3; ++a) {
+        const int lo = (int)floorf(__fmul_rn(mn[a], inv));
+        const int hi = (int)floorf(__fmul_rn(mx[a], inv));
+        s.min_b[a] = lo;
+        s.div_b[a] = hi - lo + 1;
+        cells *= (long long)(hi - lo + 1);
+        if (cells > 2147483647ll) bad = true;
+    }
+    if (bad) { s.status = CD_ERR_LEAF_TOO_SMALL; s.n_c = 0; return; }
+    int bits = 1;
+    while (bits < 31 && (1ll << bits) < cells) ++bits;
+    s.key_bits = bits;
+}
+
+// ---- pass B: ordered compaction + voxel key -------------------------------------------
+__global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__ in, size_t stride, int N, int pitch,
+                                                        int rgb_off, CropLimits lim, int T, float leaf,
+                                                        const FrameState* __restrict__ fs,
+                                                        const int* __restrict__ tile_off, float4* __restrict__ cpt,
+                                                        uint32_t* __restrict__ keys) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (fs[f].n_c <= 0) return;
+    const size_t fbase = (size_t)f * N;        // input records
+    const size_t obase = (size_t)f * pitch;    // internal arrays
+    const int base = tile * TILE + w * WAVE_SPAN;
+    float px[ITEMS], py[ITEMS], pz[ITEMS];
+    uint32_t pc[ITEMS];
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE + lane;
+        bool keep = false;
+        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0;
+        if (e < N) {
+            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
+            keep = crop_keep(px[j], py[j], pz[j], lim);
+        }
+        bal[j] = __ballot(keep);
+        wtot += __popcll(bal[j]);
+    }
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    int pos = tile_off[(size_t)f * T + tile];
+    for (int k = 0; k < w; ++k) pos += s_cnt[k];
+    const float inv = __fdiv_rn(1.0f, leaf);
+    const int mb0 = fs[f].min_b[0], mb1 = fs[f].min_b[1], mb2 = fs[f].min_b[2];
+    const int d0 = fs[f].div_b[0], d01 = fs[f].div_b[0] * fs[f].div_b[1];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) {
+            const int r = pos + __popcll(bal[j] & lt);
+            const int i0 = (int)__fsub_rn(floorf(__fmul_rn(px[j], inv)), (float)mb0);
+            const int i1 = (int)__fsub_rn(floorf(__fmul_rn(py[j], inv)), (float)mb1);
+            const int i2 = (int)__fsub_rn(floorf(__fmul_rn(pz[j], inv)), (float)mb2);
+            cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
+            keys[obase + r] = (uint32_t)(i0 + i1 * d0 + i2 * d01);
+        }
+        pos += __popcll(bal[j]);
+    }
+}
+
+// ---- voxel run heads in the sorted key array -------------------------------------------
+__device__ __forceinline__ bool is_head(const uint32_t* __restrict__ k, int e, int n) {
+    return e < n && (e == 0 || k[e] != k[e - 1]);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_voxel_heads_count(const uint32_t* __restrict__ keys, int N, int T,
+                                                             const FrameState* __restrict__ fs,
+                                                             int* __restrict__ tile_cnt) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_c;
+    if (tile * TILE >= n) return;
+    const uint32_t* k = keys + (size_t)f * N;
+    const int base = tile * TILE + w * WAVE_SPAN;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) cnt += __popcll(__ballot(is_head(k, base + j * WAVE + lane, n)));
+    if (lane == 0) s_cnt[w] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) tile_cnt[(size_t)f * T + tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// One thread per voxel: walks its run in sorted order (= ascending input order inside the
+// voxel, rule C2) and forms the float32 centroid exactly as PCL does: sequential sums,
+// one division by the float count.  rgb is averaged as three float channels and re-packed.
+__global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __restrict__ keys,
+                                                          const uint32_t* __restrict__ vals,
+                                                          const float4* __restrict__ cpt, int N, int T, int rgb_on,
+                                                          const FrameState* __restrict__ fs,
+                                                          const int* __restrict__ tile_off, float4* __restrict__ vox) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_c;
+    if (tile * TILE >= n) return;
+    const size_t fbase = (size_t)f * N;
+    const uint32_t* k = keys + fbase;
+    const uint32_t* v = vals + fbase;
+    const int base = tile * TILE + w * WAVE_SPAN;
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
+        wtot += __popcll(bal[j]);
+    }
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    int pos = tile_off[(size_t)f * T + tile];
+    for (int q = 0; q < w; ++q) pos += s_cnt[q];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) {
+            const int r = pos + __popcll(bal[j] & lt);
+            int e = base + j * WAVE + lane;
+            const uint32_t key = k[e];
+            float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+            int cnt = 0;
+            do {
+                const float4 p = cpt[fbase + v[e]];
+                sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z);
+                if (rgb_on) {
+                    const uint32_t u = __float_as_uint(p.w);
+                    cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff);
+                }
+                ++cnt; ++e;
+            } while (e < n && k[e] == key);
+            const float c = (float)cnt;
+            uint32_t packed = 0;
+            if (rgb_on) {
+                const int R = (int)__fdiv_rn(cr, c), G = (int)__fdiv_rn(cg, c), B = (int)__fdiv_rn(cb, c);
+                packed = ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+            }
+            vox[fbase + r] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
+        }
+        pos += __popcll(bal[j]);
+    }
+}
+
+// ---- host launchers ---------------------------------------------------------------------
+void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
+                       FrameState* fs, int* tile_cnt) {
+    const int Tin = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL(k_crop_count, dim3(Tin, F), dim3(BLOCK), 0, s, (const char*)in, stride, N, rgb_off, lim, T, fs, tile_cnt);
+}
+void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(rows), dim3(BLOCK), 0, s, counts, T, totals, total_pitch);
+}
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf) {
+    hipLaunchKernelGGL(k_voxel_setup, dim3((F + 63) / 64), dim3(64), 0, s, fs, F, leaf);
+}
+void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                         int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys) {
+    const int Tin = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL(k_crop_compact, dim3(Tin, F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, leaf,
+                       fs, tile_off, cpt, keys);
+}
+void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
+                              int* tile_cnt) {
+    hipLaunchKernelGGL(k_voxel_heads_count, dim3(Tact, F), dim3(BLOCK), 0, s, keys, N, T, fs, tile_cnt);
+}
+void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
+                           int T, int Tact, int rgb_on, const FrameState* fs, const int* tile_off, float4* vox) {
+    hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact, F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, rgb_on, fs, tile_off, vox);
+}
+
+}  // namespace cd

@@ -1,0 +1,56 @@
+// kernels.hpp - host-callable launchers of every HIP kernel (one .hip file per stage).
+#pragma once
+#include "common.hpp"
+
+namespace cd {
+
+// k_voxel.hip
+void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
+                       FrameState* fs, int* tile_cnt);
+void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf);
+void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                         int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
+void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
+                              int* tile_cnt);
+void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
+                           int T, int Tact, int rgb_on, const FrameState* fs, const int* tile_off, float4* vox);
+
+// k_sort.hip : segmented (per frame) stable LSD radix sort pass on (key, value) pairs
+void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
+                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist);
+
+// k_plane.hip
+void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,
+                          int h_target, const int* active, float4* models, int* valid);
+void launch_ransac_count(hipStream_t s, const float4* vox, int N, int F, int Tact, const FrameState* fs,
+                         const float4* models, const int* valid, const int* active, int h0, int h1, float thr, int* counts);
+void launch_plane_cov(hipStream_t s, const float4* vox, int N, int F, int Tact, const FrameState* fs, const float4* model,
+                      const int* have, float thr, unsigned long long* sums);
+void launch_plane_flag_count(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
+                             const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
+                             float z2hi, int* cnt_plane, int* cnt_obj);
+void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
+                            const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
+                            float z2hi, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj);
+
+// k_cluster.hip
+void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
+                          int* head, int* next, int* parent, int* csize, int* rank_of_root);
+void launch_cluster_hook(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
+                         float r2, const int* head, const int* next, int* parent);
+void launch_cluster_flatten(hipStream_t s, int N, int F, int Tact, const FrameState* fs, int* parent, int* csize);
+void launch_cluster_rank(hipStream_t s, int N, int F, FrameState* fs, int enable, int min_sz, int max_sz,
+                         const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted);
+void launch_label_count(hipStream_t s, int N, int F, int T, int Tact, const FrameState* fs, int enable, const int* parent,
+                        const int* rank_of_root, int* label, int* tile_cnt);
+void launch_label_scatter(hipStream_t s, const float4* obj, int N, int F, int T, int Tact, const FrameState* fs,
+                          const int* label, const int* tile_off, float4* src0, float4* src);
+
+// k_icp.hip
+void launch_icp_iter(hipStream_t s, int it, int n_work, const IcpWork* work, const IcpCluster* cl, IcpState* st,
+                     unsigned long long* acc, const float4* tpl, float4* src, IcpParams prm);
+void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
+                        int parity, unsigned long long* accf, const float4* tpl, const float4* src0);
+
+}  // namespace cd

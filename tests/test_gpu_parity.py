@@ -1,0 +1,265 @@
+"""GPU parity tests: every stage and the fused batch path of libcuboid_hip.so (called through
+the C-ABI) against the CPU oracle on the same inputs, and against the committed goldens.
+Bit-exact for voxel clouds, plane coefficients/indices, cluster labels, ICP iteration counts
+and transforms; the north-star tolerance (pose Frobenius < 1e-4) is asserted as well."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, rot_xyz
+from perception_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4   # BASELINE.json north_star: ICP pose Frobenius error < 1e-4
+
+
+@pytest.fixture(scope="module")
+def ctx(template):
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=4)
+    c.set_template(0, template)
+    yield c
+    c.close()
+
+
+def _same_cluster(a, b):
+    assert (a.size, a.iterations, a.converged, a.accepted) == (b.size, b.iterations, b.converged, b.accepted)
+    pa, pb = np.array(a.pose).reshape(4, 4), np.array(b.pose).reshape(4, 4)
+    assert np.linalg.norm(pa - pb) < POSE_TOL
+    assert list(a.T) == list(b.T), "final transformation not bit-identical"
+    assert a.fitness == b.fitness
+
+
+def test_crop_voxel_bit_exact(ctx, O, frames4):
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    for leaf in (0.005, 0.01, 0.001):
+        prm.leaf_size = leaf
+        f = frames4[1]
+        vox, rgb, nc = ctx.crop_voxel(f, prm, want_rgb=True)
+        st, vo, ro, nco, _ = O.crop_voxel(f, prm, want_rgb=True)
+        assert st == 0 and nc == nco and vox.shape == vo.shape
+        assert np.array_equal(vox.view(np.uint32), vo.view(np.uint32))
+        assert np.array_equal(rgb, ro)
+
+
+def test_crop_voxel_edge_cases(ctx, O):
+    prm = capi.default_params()
+    # all-NaN, single point, limits exactly on float boundaries, stride 12 (no rgb)
+    v, _, nc = ctx.crop_voxel(np.full((10, 3), np.nan, np.float32), prm)
+    assert len(v) == 0 and nc == 0
+    one = np.array([[0.1, 0.0, 0.5]], np.float32)
+    v, _, nc = ctx.crop_voxel(one, prm)
+    assert nc == 1 and np.array_equal(v, one)
+    f = np.float32
+    xs = np.array([0.2, np.nextafter(f(0.2), f(0)), -0.2, np.nextafter(f(-0.2), f(0)), 0.0], np.float32)
+    pts = np.stack([xs, np.zeros(5, np.float32), np.full(5, 0.9, np.float32)], 1)
+    pts[4, 2] = np.nextafter(f(0.9), f(0))
+    v, _, nc = ctx.crop_voxel(pts, prm)
+    st, vo, _, nco, _ = O.crop_voxel(pts, prm)
+    assert nc == nco and np.array_equal(v, vo)
+    prm.leaf_size = 1e-5
+    big = np.array([[-0.19, -5, 0.1], [0.19, 5, 0.89]], np.float32)
+    with pytest.raises(capi.CuboidError) as e:
+        ctx.crop_voxel(big, prm)
+    assert e.value.status == capi.CD_ERR_LEAF_TOO_SMALL
+
+
+def test_voxel_random_ragged_cloud(ctx, O):
+    """Unorganized cloud, many points per voxel, 20-byte records."""
+    rng = np.random.RandomState(3)
+    n = 50000
+    rec = np.zeros((n, 5), np.float32)
+    rec[:, :3] = rng.uniform([-0.25, -0.3, -0.1], [0.25, 0.3, 1.0], (n, 3))
+    rec[rng.rand(n) < 0.05, 1] = np.inf
+    rec[:, 4] = rng.randint(0, 1 << 24, n).astype(np.uint32).view(np.float32)
+    prm = capi.default_params()
+    prm.leaf_size = 0.02
+    prm.rgb_offset = 16
+    vox, rgb, nc = ctx.crop_voxel(rec, prm, want_rgb=True)
+    st, vo, ro, nco, _ = O.crop_voxel(rec, prm, want_rgb=True)
+    assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+
+
+def test_segment_plane_bit_exact(ctx, O, frames4):
+    prm = capi.default_params()
+    for f in frames4[:2]:
+        st, vo, _, _, _ = O.crop_voxel(f, prm)
+        s1, c1, i1, it1 = ctx.segment_plane(vo, prm)
+        s0, c0, i0, it0 = O.segment_plane(vo, prm)
+        assert s1 == s0 == 0 and it1 == it0
+        assert np.array_equal(c1.view(np.uint32), c0.view(np.uint32))
+        assert np.array_equal(i1, i0)
+
+
+def test_segment_plane_hard_cases(ctx, O):
+    prm = capi.default_params()
+    rng = np.random.RandomState(11)
+    # no dominant plane: needs many hypotheses (several sampler rounds)
+    clutter = rng.uniform(-0.3, 0.3, (4000, 3)).astype(np.float32)
+    s1, c1, i1, it1 = ctx.segment_plane(clutter, prm)
+    s0, c0, i0, it0 = O.segment_plane(clutter, prm)
+    assert (s1, it1) == (s0, it0) and np.array_equal(i1, i0) and np.array_equal(c1.view(np.uint32), c0.view(np.uint32))
+    # fewer than 3 points: no model
+    s1, *_ = ctx.segment_plane(np.zeros((2, 3), np.float32), prm)
+    assert s1 == capi.CD_ERR_NO_MODEL
+    # axis-aligned collinear cloud: PCL runs max_iterations+1 hypotheses and returns NaN coefficients
+    line = np.zeros((50, 3), np.float32)
+    line[:, 0] = np.arange(50) * 0.01
+    s1, c1, i1, it1 = ctx.segment_plane(line, prm)
+    s0, c0, i0, it0 = O.segment_plane(line, prm)
+    assert (s1, it1, len(i1)) == (s0, it0, len(i0)) == (0, 1001, 0) and np.isnan(c1).all()
+    # optimize off
+    prm.plane_optimize = 0
+    pts = np.concatenate([np.c_[rng.uniform(-.2, .2, (2000, 2)), np.full(2000, 0.5)], rng.uniform(-.2, .6, (300, 3))]).astype(np.float32)
+    s1, c1, i1, it1 = ctx.segment_plane(pts, prm)
+    s0, c0, i0, it0 = O.segment_plane(pts, prm)
+    assert (s1, it1) == (s0, it0) and np.array_equal(i1, i0) and np.array_equal(c1.view(np.uint32), c0.view(np.uint32))
+
+
+def _blob(center, n, r, rng):
+    return (np.asarray(center) + rng.uniform(-r, r, (n, 3))).astype(np.float32)
+
+
+def test_cluster_labels_bit_exact(ctx, O, frames4, template):
+    prm = capi.default_params()
+    r = O.process_frame(frames4[2], prm, template, want_clouds=True)
+    lab, sizes, k = ctx.cluster(r["objects"], prm)
+    assert k == r["result"].n_clusters and np.array_equal(lab, r["labels"])
+    rng = np.random.RandomState(5)
+    pts = np.concatenate([_blob([0, 0, .5], 199, .01, rng), _blob([.2, 0, .5], 200, .01, rng), _blob([.4, 0, .5], 300, .01, rng),
+                          _blob([.6, 0, .5], 300, .01, rng), rng.uniform(-1, 1, (3000, 3)).astype(np.float32)])
+    pts = pts[rng.permutation(len(pts))]
+    for mn in (200, 1, 5):
+        prm.cluster_min_size = mn
+        lab, sizes, k = ctx.cluster(pts, prm, sizes_capacity=8192)
+        l0, s0, k0 = O.cluster(pts, prm, mode=1, sizes_capacity=8192)
+        assert k == k0 and np.array_equal(lab, l0) and np.array_equal(sizes, s0)
+    # strict radius on a chain, max size drops the whole component
+    chain = np.zeros((5, 3), np.float32)
+    chain[:, 0] = np.cumsum([0, 0.019, 0.019, 0.02, 0.019])
+    prm.cluster_min_size, prm.cluster_max_size = 1, 100
+    lab, sizes, k = ctx.cluster(chain, prm)
+    l0, s0, k0 = O.cluster(chain, prm, mode=0)
+    assert k == k0 and np.array_equal(lab, l0)
+    g = np.stack(np.meshgrid(np.arange(160), np.arange(157)), -1).reshape(-1, 2) * 0.01
+    big = np.zeros((len(g), 3), np.float32)
+    big[:, :2] = g
+    prm.cluster_min_size, prm.cluster_max_size = 200, 25119
+    lab, sizes, k = ctx.cluster(big, prm)
+    assert k == 0 and (lab == -1).all()
+    prm.cluster_max_size = 25120
+    lab, sizes, k = ctx.cluster(big, prm)
+    assert k == 1 and sizes[0] == 25120 and (lab == 0).all()
+
+
+def test_icp_bit_exact_and_known_answer(ctx, O, template, frames4):
+    prm = capi.default_params()
+    r = O.process_frame(frames4[0], prm, template, want_clouds=True)
+    src = r["objects"][r["labels"] == 0]
+    st, res, al = ctx.icp(0, src, prm, want_aligned=True)
+    s0, r0, a0 = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert st == s0 == 0
+    _same_cluster(res, r0)
+    assert np.array_equal(al.view(np.uint32), a0.view(np.uint32))
+    # known answer: sub-grid-pitch rigid offset of the template itself
+    R = rot_xyz(np.deg2rad(0.2), np.deg2rad(-0.15), np.deg2rad(0.25))
+    t = np.array([0.0004, -0.0003, 0.0005])
+    Tk = np.eye(4)
+    Tk[:3, :3], Tk[:3, 3] = R, t
+    src = (template[::3].astype(np.float64) @ R.T + t).astype(np.float32)
+    prm.icp_euclidean_fitness_epsilon = 1e-9
+    st, res, _ = ctx.icp(0, src, prm)
+    assert st == 0 and res.converged == 1
+    assert np.linalg.norm(np.array(res.pose).reshape(4, 4) - Tk) < POSE_TOL
+    s0, r0, _ = O.icp(template, src, prm, nn_mode=1)
+    _same_cluster(res, r0)
+    # too few points
+    st, res, _ = ctx.icp(0, template[:2], prm)
+    assert st == capi.CD_ERR_FEW_CORRESPONDENCES and res.converged == 0
+
+
+def test_icp_large_template_and_real_cluster(ctx, O):
+    """Template spanning many LDS chunks (21400 points, like the reference's 6-face template)
+    and a real D435 cluster from the reference tree as the source."""
+    from perception_amd import pcd, templates
+    big = templates.template_xyz32(0.2, 0.1, 0.075, 0.001)[:21400]
+    ctx.set_template(1, big)
+    X = pcd.read_xyz(os.path.join(GOLDEN, "eraser_ascii.pcd"))
+    prm = capi.default_params()
+    src = (X - X.mean(0) + [0.01, 0.0, 0.0]).astype(np.float32)
+    st, res, _ = ctx.icp(1, src, prm)
+    s0, r0, _ = O.icp(big, src, prm, nn_mode=1)
+    assert st == s0 == 0
+    _same_cluster(res, r0)
+
+
+def test_batch_matches_oracle_and_goldens(ctx, O, template, frames4):
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    batch = np.stack(frames4, 0)
+    res, pi, lb = ctx.process_batch(batch, prm, want_indices=True)
+    gold = json.load(open(os.path.join(GOLDEN, "frames_golden.json")))["frames"]
+    for f in range(4):
+        o = O.process_frame(frames4[f], prm, template, want_clouds=True)
+        ro, rg, e = o["result"], res[f], gold[f]
+        for k in ("status", "n_cropped", "n_voxels", "n_plane", "n_objects", "n_clusters", "ransac_iterations"):
+            assert getattr(rg, k) == getattr(ro, k), (f, k)
+        assert [float(x).hex() for x in rg.plane] == [float(x).hex() for x in ro.plane] == e["plane_hex"]
+        assert np.array_equal(pi[f][:rg.n_plane], o["plane_inliers"]) and (pi[f][rg.n_plane:] == -1).all()
+        assert np.array_equal(lb[f][:rg.n_objects], o["labels"]) and (lb[f][rg.n_objects:] == -1).all()
+        assert hashlib.sha256(pi[f][:rg.n_plane].tobytes()).hexdigest() == e["plane_inliers_sha256"]
+        assert hashlib.sha256(lb[f][:rg.n_objects].tobytes()).hexdigest() == e["labels_sha256"]
+        for k in range(min(rg.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+            _same_cluster(rg.clusters[k], ro.clusters[k])
+            assert [float(x).hex() for x in rg.clusters[k].T] == e["clusters"][k]["T_hex"]
+
+
+def test_batch_cuboid_flavour_and_object_launch_params(ctx, O, template, frames4):
+    """cluster_enable=0 (cuboid_detection: ICP on the whole extracted cloud) and the
+    object_detection launch values (leaf 0.001, threshold 0.01)."""
+    prm = capi.default_params()
+    prm.cluster_enable = 0
+    prm.crop2_enable = 0
+    res, pi, lb = ctx.process_batch(np.stack(frames4[:2], 0), prm, want_indices=True)
+    for f in range(2):
+        o = O.process_frame(frames4[f], prm, template, want_clouds=True)
+        assert res[f].n_clusters == o["result"].n_clusters == 1
+        _same_cluster(res[f].clusters[0], o["result"].clusters[0])
+    prm = capi.default_params()
+    prm.leaf_size = 0.001
+    prm.plane_distance_threshold = 0.01
+    res, pi, lb = ctx.process_batch(frames4[3][None], prm, want_indices=True)
+    o = O.process_frame(frames4[3], prm, template, want_clouds=True)
+    rg, ro = res[0], o["result"]
+    assert (rg.n_voxels, rg.n_plane, rg.n_objects, rg.n_clusters) == (ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters)
+    assert np.array_equal(pi[0][:rg.n_plane], o["plane_inliers"]) and np.array_equal(lb[0][:rg.n_objects], o["labels"])
+    for k in range(min(rg.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+        _same_cluster(rg.clusters[k], ro.clusters[k])
+
+
+def test_batch_is_idempotent_and_frame_independent(ctx, frames4):
+    """Size-independent properties: running twice gives identical bytes; a frame's record does
+    not depend on its position in the batch or on its neighbours."""
+    prm = capi.default_params()
+    a, _, _ = ctx.process_batch(np.stack(frames4, 0), prm)
+    b, _, _ = ctx.process_batch(np.stack(frames4[::-1], 0), prm)
+    c, _, _ = ctx.process_batch(np.stack(frames4, 0), prm)
+    A, B, Cc = capi.results_to_array(a), capi.results_to_array(b), capi.results_to_array(c)
+    assert np.array_equal(A, Cc)
+    assert np.array_equal(A, B[::-1])
+
+
+def test_empty_and_degenerate_frames_in_batch(ctx, O, template, frames4):
+    prm = capi.default_params()
+    nanf = np.full_like(frames4[0], np.nan)
+    planeonly = synth.render(dict(synth.scene_for(0), boxes=[]))
+    res, _, _ = ctx.process_batch(np.stack([nanf, frames4[0], planeonly], 0), prm)
+    assert res[0].n_cropped == 0 and res[0].n_voxels == 0 and res[0].status == capi.CD_ERR_NO_MODEL and res[0].n_clusters == 0
+    o1 = O.process_frame(frames4[0], prm, template)["result"]
+    _same_cluster(res[1].clusters[0], o1.clusters[0])
+    o2 = O.process_frame(planeonly, prm, template)["result"]
+    assert (res[2].n_voxels, res[2].n_plane, res[2].n_objects, res[2].n_clusters) == (o2.n_voxels, o2.n_plane, o2.n_objects, o2.n_clusters)
