@@ -181,6 +181,7 @@ typedef struct cd_timing {
     int32_t icp_kernel_launches;
     int32_t icp_pair_tests_lo, icp_pair_tests_hi; /* 64-bit count of point-pair distance tests */
     int64_t algorithmic_bytes;                    /* B_alg of SURVEY 8(d) for this batch */
+    int64_t icp_algorithmic_bytes;                /* the S6 term of B_alg: sum 12*M + 12*N_s*(I_c+1) */
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

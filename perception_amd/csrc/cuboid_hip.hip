@@ -425,7 +425,9 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
         balg += 12ll * N + 12ll * s.n_v + 12ll * s.n_v * (rounds + 3) + 4ll * s.n_v + 16ll * s.n_o + 200ll * s.n_k;
         for (int k = 0; k < kk; ++k) {
             fill_cluster_result(c, first_cl[f] + k, p, &r.clusters[k]);
-            balg += 12ll * c->tpl_m[slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
+            const long long b = 12ll * c->tpl_m[slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
+            balg += b;
+            c->timing.icp_algorithmic_bytes += b;
         }
     }
     if (plane_inliers || labels) {

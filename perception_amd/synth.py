@@ -80,38 +80,53 @@ def scene_for(index, k_obj=None, seed=None):
     return dict(seed=seed, n=n, p0=p0, e1=e1, e2=e2, boxes=boxes)
 
 
+_RAY_CACHE = {}
+
+
+def _ray_dirs(width, height):
+    key = (width, height)
+    if key not in _RAY_CACHE:
+        sx, sy = width / float(WIDTH), height / float(HEIGHT)
+        v, u = np.divmod(np.arange(width * height), width)
+        _RAY_CACHE[key] = ((u - CX * sx) / (FX * sx), (v - CY * sy) / (FY * sy))
+    return _RAY_CACHE[key]
+
+
 def render(scene, width=WIDTH, height=HEIGHT, noise=True, invalid_frac=0.02):
     """(height*width, 4) float32 records x,y,z,rgb(packed uint32 viewed as float32)."""
     npx = width * height
-    sx, sy = width / float(WIDTH), height / float(HEIGHT)
-    v, u = np.divmod(np.arange(npx), width)
-    d = np.stack([(u - CX * sx) / (FX * sx), (v - CY * sy) / (FY * sy), np.ones(npx)], axis=1)
+    dx, dy = _ray_dirs(width, height)       # ray direction = (dx, dy, 1)
     nrm, p0 = scene["n"], scene["p0"]
-    denom = d @ nrm
+    denom = dx * nrm[0] + dy * nrm[1] + nrm[2]
     with np.errstate(divide="ignore", invalid="ignore"):
         t = np.where(denom < -1e-9, (p0 @ nrm) / denom, np.inf)
     color = np.full(npx, _pack_rgb(150, 140, 130), dtype=np.uint32)
     for k, bx in enumerate(scene["boxes"]):
-        o = -(bx["R"].T @ bx["c"])          # ray origin (camera centre) in box frame
-        dd = d @ bx["R"]                    # ray directions in box frame
+        R = bx["R"]
+        o = -(R.T @ bx["c"])                # ray origin (camera centre) in box frame
+        tn = np.full(npx, -np.inf)
+        tf = np.full(npx, np.inf)
         with np.errstate(divide="ignore", invalid="ignore"):
-            t1 = (-bx["half"] - o) / dd
-            t2 = (bx["half"] - o) / dd
-        tn = np.max(np.minimum(t1, t2), axis=1)
-        tf = np.min(np.maximum(t1, t2), axis=1)
+            for a in range(3):              # slab test, one box axis at a time
+                dd = dx * R[0, a] + dy * R[1, a] + R[2, a]
+                t1 = (-bx["half"][a] - o[a]) / dd
+                t2 = (bx["half"][a] - o[a]) / dd
+                np.maximum(tn, np.minimum(t1, t2), out=tn)
+                np.minimum(tf, np.maximum(t1, t2), out=tf)
         hit = (tn <= tf) & (tn > 0) & (tn < t)
         t = np.where(hit, tn, t)
         color = np.where(hit, _pack_rgb(200, 30 + 60 * k, 40), color)
-    z = t.copy()
+    z = t
     seed = scene["seed"]
     if noise:
         z = z + 0.001 * (z / 0.5) ** 2 * _normal(seed, 100, npx)
-    pts = d * z[:, None]
     bad = ~np.isfinite(z) | (z <= 0)
     if invalid_frac > 0:
         bad |= _uniform(seed, 200, npx) < invalid_frac
     out = np.empty((npx, 4), dtype=np.float32)
-    out[:, :3] = pts.astype(np.float32)
+    out[:, 0] = dx * z
+    out[:, 1] = dy * z
+    out[:, 2] = z
     out[bad, :3] = np.nan
     out[:, 3] = color.view(np.float32)
     return out
