@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 3: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--latency", action="store_true", help="also measure single-frame latency (BASELINE config 2) after the timed region")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,8 +138,8 @@ def main():
     pairs = (t.icp_pair_tests_hi << 32) | (t.icp_pair_tests_lo & 0xffffffff)
     balg, icp_balg = t.algorithmic_bytes, t.icp_algorithmic_bytes
     one = (capi.CdFrameResult * 1)()
-    lat = []
-    for _ in range(5):
+    lat = [float("nan")]
+    for _ in range(5 if args.latency else 0):
         torch.cuda.synchronize()
         a = time.perf_counter()
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, 1, prm, results=one)
@@ -177,7 +178,7 @@ def main():
             "stage_ms_per_step": {"crop_voxel": stage[0] / args.steps, "plane": stage[1] / args.steps,
                                   "extract_cluster": stage[2] / args.steps, "icp": stage[3] / args.steps,
                                   "device_total": stage[4] / args.steps},
-            "single_frame_ms": {"median": float(np.median(lat)), "min": float(np.min(lat))},
+            "single_frame_ms": ({"median": float(np.median(lat[1:])), "min": float(np.min(lat[1:]))} if args.latency else None),
             "icp": {"clusters": ncl, "accepted": int(acc), "mean_iterations": float(np.mean(iters)) if iters else 0.0,
                     "max_iterations": int(max(iters)) if iters else 0, "frames": nfr},
         }

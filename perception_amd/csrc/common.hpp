@@ -23,6 +23,7 @@ constexpr int SAMPLER_MAP = 8192;          // LDS sparse shuffle map (open addre
 constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses at most kept per frame
 constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
 constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
+constexpr int ICP_SUB = 64;                // template run length that carries one pruning box
 
 // Per-frame scalars that live on the device and are mirrored to pinned host memory.
 struct FrameState {

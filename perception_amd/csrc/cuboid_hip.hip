@@ -45,7 +45,8 @@ struct cd_context {
     int *d_plane_idx = nullptr, *d_head = nullptr, *d_next = nullptr, *d_parent = nullptr, *d_csize = nullptr,
         *d_rank = nullptr, *d_cand = nullptr, *d_sizes = nullptr, *d_label = nullptr;
     // templates
-    float4* d_tpl = nullptr;
+    float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
+    int* d_nn = nullptr;                                          // last NN index of every ICP source point
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
     // ICP
@@ -289,7 +290,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int group = 16;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_src, ip);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, ip);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
@@ -298,7 +299,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
-    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_src0);
+    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src0, c->d_nn);
     HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -504,7 +505,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -546,6 +547,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_rank, FN) == hipSuccess && dalloc(&c->d_cand, FN) == hipSuccess && dalloc(&c->d_sizes, FN) == hipSuccess && dalloc(&c->d_label, FN) == hipSuccess;
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
+    ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
+    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess;
     const size_t ncl = F * KICP;
     c->work_cap = (int)(F * (N / BLOCK + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
@@ -573,14 +576,32 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
     hipSetDevice(c->device);
     // templates are appended; re-setting a slot with a template that fits reuses its space
     int off;
+    const int m_pad = (m + ICP_SUB - 1) / ICP_SUB * ICP_SUB;   // slots start on a 64-point run boundary
     if (c->tpl_m[slot] >= m) off = c->tpl_off[slot];
     else {
-        if (c->tpl_used + m > c->tpl_cap) return fail(c, CD_ERR_CAPACITY, "template storage exhausted");
+        if (c->tpl_used + m_pad > c->tpl_cap) return fail(c, CD_ERR_CAPACITY, "template storage exhausted");
         off = c->tpl_used;
-        c->tpl_used += m;
+        c->tpl_used += m_pad;
     }
     int st = upload_points(c, xyz, stride, m, c->d_tpl + off);
     if (st) return st;
+    {   // axis-aligned box of every run of 64 consecutive template points (exact float min/max)
+        const int nrun = m_pad / ICP_SUB;
+        std::vector<float4> lo((size_t)nrun), hi((size_t)nrun);
+        const char* b = (const char*)xyz;
+        for (int r = 0; r < nrun; ++r) {
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int i = r * ICP_SUB; i < std::min(m, (r + 1) * ICP_SUB); ++i) {
+                float v[3];
+                std::memcpy(v, b + (size_t)i * stride, 12);
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
+            }
+            lo[r] = make_float4(mn[0], mn[1], mn[2], 0.f);
+            hi[r] = make_float4(mx[0], mx[1], mx[2], 0.f);
+        }
+        HIPCHK(c, hipMemcpy(c->d_tlo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(c->d_thi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+    }
     c->tpl_off[slot] = off;
     c->tpl_m[slot] = m;
     return CD_OK;

@@ -170,32 +170,84 @@ __device__ __forceinline__ void xform(const float* T, float x, float y, float z,
     oz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
 }
 
-// exact NN of (x,y,z) over the template, staged through LDS; every thread of the block calls it
-__device__ __forceinline__ void nn_search(const float4* __restrict__ tpl, int m, float4* s_tpl, bool active, float x,
-                                          float y, float z, float& best, int& bi) {
-    best = 3.402823466e38f;
-    bi = 0;
+#ifdef CD_STATS
+__device__ unsigned long long g_icp_stats[4];
+extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_stats), sizeof(g_icp_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+// Exact NN of (x,y,z) over the template, staged through LDS; every thread of the block calls it.
+//
+// Pruning is exact, not approximate.  The template is cut into runs of 64 consecutive points,
+// each with an axis-aligned box [lo,hi] (built at cd_set_template).  For a query q the bound
+//   e_a = max(lo_a - q_a, q_a - hi_a, 0),  lb = (e_x*e_x + e_y*e_y) + e_z*e_z
+// evaluated with the canonical association satisfies lb <= d2(q,p) for EVERY p in the run in
+// float arithmetic, because each step (rounded subtraction, square, rounded sum) is monotone in
+// |component|.  A run is skipped only when lb > best for all 64 lanes (wave vote), so no
+// candidate that could improve on or tie the current best is ever dropped.
+// Seeding: (best, bi) enter as (nextafter(d(q, seed)), seed); an ascending strict-< scan from
+// that state still ends at the lowest index achieving the global minimum (rule C5), and the run
+// holding the true NN can never be pruned since its lb <= d_min < best.
+__device__ __forceinline__ void nn_search(const float4* __restrict__ tpl, const float4* __restrict__ blo,
+                                          const float4* __restrict__ bhi, int m, float4* s_tpl, float4* s_lo,
+                                          float4* s_hi, float x, float y, float z, float& best, int& bi) {
     for (int c0 = 0; c0 < m; c0 += ICP_TPL_CHUNK) {
         const int cn = min(ICP_TPL_CHUNK, m - c0);
+        const int nsub = (cn + ICP_SUB - 1) / ICP_SUB;
         __syncthreads();
         for (int k = threadIdx.x; k < cn; k += BLOCK) s_tpl[k] = tpl[c0 + k];
+        if (threadIdx.x < nsub) {
+            s_lo[threadIdx.x] = blo[c0 / ICP_SUB + threadIdx.x];
+            s_hi[threadIdx.x] = bhi[c0 / ICP_SUB + threadIdx.x];
+        }
         __syncthreads();
-        if (active) {
+        for (int s = 0; s < nsub; ++s) {
+            const float4 L = s_lo[s], H = s_hi[s];
+            const float ex = fmaxf(fmaxf(L.x - x, x - H.x), 0.f);
+            const float ey = fmaxf(fmaxf(L.y - y, y - H.y), 0.f);
+            const float ez = fmaxf(fmaxf(L.z - z, z - H.z), 0.f);
+            const float lb = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+#ifdef CD_STATS
+            if ((threadIdx.x & 63) == 0) atomicAdd(&g_icp_stats[0], 1ull);
+            { const unsigned long long need = __popcll(__ballot(lb <= best)); if ((threadIdx.x & 63) == 0 && need) { atomicAdd(&g_icp_stats[1], 1ull); atomicAdd(&g_icp_stats[2], need); } }
+#endif
+            if (__any(lb <= best)) {                       // wave-uniform; inactive lanes carry best = -1
+                const int j0 = s * ICP_SUB, j1 = min(j0 + ICP_SUB, cn);
 #pragma unroll 8
-            for (int j = 0; j < cn; ++j) {
-                const float4 t = s_tpl[j];
-                const float d = dist2(x, y, z, t.x, t.y, t.z);
-                if (d < best) { best = d; bi = c0 + j; }   // strict: lowest index wins ties (C5)
+                for (int j = j0; j < j1; ++j) {
+                    const float4 t = s_tpl[j];
+                    const float d = dist2(x, y, z, t.x, t.y, t.z);
+                    if (d < best) { best = d; bi = c0 + j; }   // strict: lowest index wins ties (C5)
+                }
             }
         }
     }
 }
 
+
+// seed for a search that has no previous neighbour: best over the first point of every run
+__device__ __forceinline__ void nn_seed_coarse(const float4* __restrict__ tpl, int m, float x, float y, float z,
+                                               float& best, int& bi) {
+    best = 3.402823466e38f;
+    bi = 0;
+    for (int j = 0; j < m; j += ICP_SUB) {
+        const float4 t = tpl[j];
+        const float d = dist2(x, y, z, t.x, t.y, t.z);
+        if (d < best) { best = d; bi = j; }
+    }
+}
+__device__ __forceinline__ float next_up_nonneg(float d) { return __uint_as_float(__float_as_uint(d) + 1u); }
+
 __global__ void __launch_bounds__(BLOCK) k_icp_iter(int it, const IcpWork* __restrict__ work,
                                                     const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
                                                     unsigned long long* __restrict__ acc, const float4* __restrict__ tpl,
-                                                    float4* __restrict__ src, IcpParams prm) {
+                                                    const float4* __restrict__ tlo, const float4* __restrict__ thi,
+                                                    float4* __restrict__ src, int* __restrict__ nn, IcpParams prm) {
     __shared__ float4 s_tpl[ICP_TPL_CHUNK];
+    __shared__ float4 s_lo[ICP_TPL_CHUNK / ICP_SUB], s_hi[ICP_TPL_CHUNK / ICP_SUB];
     __shared__ float s_T[16];
     __shared__ int s_done;
     const IcpWork wk = work[blockIdx.x];
@@ -262,9 +314,21 @@ __global__ void __launch_bounds__(BLOCK) k_icp_iter(int it, const IcpWork* __res
         }
     }
     if (s_done) return;
-    float best;
-    int bi;
-    nn_search(tpl + c.tpl_off, c.tpl_m, s_tpl, active, x, y, z, best, bi);
+    float best = -1.0f;   // inactive lanes never vote for a run and never update
+    int bi = 0;
+    const float4* tp = tpl + c.tpl_off;
+    if (active) {
+        if (it > 0) {
+            bi = nn[c.src_off + i];                    // previous iteration's neighbour
+            const float4 q0 = tp[bi];
+            best = dist2(x, y, z, q0.x, q0.y, q0.z);
+        } else {
+            nn_seed_coarse(tp, c.tpl_m, x, y, z, best, bi);
+        }
+        best = best < 3.0e38f ? next_up_nonneg(best) : __uint_as_float(0x7f800000u);
+    }
+    nn_search(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, s_lo, s_hi, x, y, z, best, bi);
+    if (active) nn[c.src_off + i] = bi;
     unsigned long long S[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) S[k] = 0ull;
@@ -292,8 +356,11 @@ __global__ void __launch_bounds__(BLOCK) k_icp_iter(int it, const IcpWork* __res
 __global__ void __launch_bounds__(BLOCK) k_icp_fitness(const IcpWork* __restrict__ work, const IcpCluster* __restrict__ cl,
                                                        const IcpState* __restrict__ st, int parity,
                                                        unsigned long long* __restrict__ accf,
-                                                       const float4* __restrict__ tpl, const float4* __restrict__ src0) {
+                                                       const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                       const float4* __restrict__ thi, const float4* __restrict__ src0,
+                                                       const int* __restrict__ nn) {
     __shared__ float4 s_tpl[ICP_TPL_CHUNK];
+    __shared__ float4 s_lo[ICP_TPL_CHUNK / ICP_SUB], s_hi[ICP_TPL_CHUNK / ICP_SUB];
     const IcpWork wk = work[blockIdx.x];
     const IcpCluster c = cl[wk.cluster];
     const IcpState* s = st + (size_t)wk.cluster * 2 + parity;
@@ -308,23 +375,32 @@ __global__ void __launch_bounds__(BLOCK) k_icp_fitness(const IcpWork* __restrict
         for (int k = 0; k < 12; ++k) T[k] = s->Tfinal[k];
         xform(T, p.x, p.y, p.z, x, y, z);
     }
-    float best;
-    int bi;
-    nn_search(tpl + c.tpl_off, c.tpl_m, s_tpl, active, x, y, z, best, bi);
+    float best = -1.0f;
+    int bi = 0;
+    const float4* tp = tpl + c.tpl_off;
+    if (active) {
+        bi = nn[c.src_off + i];                        // last iteration's neighbour as the seed
+        const float4 q0 = tp[bi];
+        best = dist2(x, y, z, q0.x, q0.y, q0.z);
+        best = best < 3.0e38f ? next_up_nonneg(best) : __uint_as_float(0x7f800000u);
+    }
+    nn_search(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, s_lo, s_hi, x, y, z, best, bi);
     const unsigned long long v = active ? (unsigned long long)fixq(best, FIX_SHIFT_D2) : 0ull;
     const unsigned long long t = wave_sum_u64(v);
     if ((threadIdx.x & 63) == 0) atomicAdd(&accf[wk.cluster], t);
 }
 
 void launch_icp_iter(hipStream_t s, int it, int n_work, const IcpWork* work, const IcpCluster* cl, IcpState* st,
-                     unsigned long long* acc, const float4* tpl, float4* src, IcpParams prm) {
+                     unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
+                     int* nn, IcpParams prm) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_iter, dim3(n_work), dim3(BLOCK), 0, s, it, work, cl, st, acc, tpl, src, prm);
+    hipLaunchKernelGGL(k_icp_iter, dim3(n_work), dim3(BLOCK), 0, s, it, work, cl, st, acc, tpl, tlo, thi, src, nn, prm);
 }
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
-                        int parity, unsigned long long* accf, const float4* tpl, const float4* src0) {
+                        int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
+                        const float4* src0, const int* nn) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(BLOCK), 0, s, work, cl, st, parity, accf, tpl, src0);
+    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(BLOCK), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, src0, nn);
 }
 
 }  // namespace cd
