@@ -1,0 +1,90 @@
+// ground_plane_segmentation node on the HIP path.  Same node name, private params, topics and
+// message types as cuboid_detection/src/ground_plane_segmentation.cpp (params :122-135, subscribe
+// :146, publishers :149-150), so it drops into cuboid_detection/launch/ground_plane_segmentation.launch
+// unchanged.  Builds only where catkin/roscpp/pcl_conversions exist (not in this image):
+//   add_executable(ground_plane_segmentation perception_amd/cpp/ros/ground_plane_segmentation_node.cpp)
+//   target_link_libraries(ground_plane_segmentation ${catkin_LIBRARIES} cuboid_hip)
+#ifdef CUBOID_HIP_WITH_ROS
+#include <pcl_conversions/pcl_conversions.h>
+#include <pcl_msgs/ModelCoefficients.h>
+#include <ros/ros.h>
+#include <sensor_msgs/PointCloud2.h>
+
+#include "../pcl_compat.hpp"
+
+static ros::Publisher pcl_pub, coef_pub;
+static bool invert;
+static double voxel_size, distance_threshold;
+static std::string input_topic, output_topic, coefficients_topic;
+
+static int field_offset(const sensor_msgs::PointCloud2& m, const char* name) {
+    for (const auto& f : m.fields) if (f.name == name) return (int)f.offset;
+    return -1;
+}
+
+void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
+    // The PointCloud2 blob goes to the device as it is: x,y,z float32 at offsets 0/4/8, stride = point_step.
+    cd_context* ctx = pclhip::Device::instance((int)(input->width * input->height)).ctx();
+    cd_params prm;
+    cd_default_params(&prm);
+    prm.leaf_size = (float)voxel_size;
+    prm.plane_distance_threshold = distance_threshold;
+    prm.extract_negative = invert ? 1 : 0;
+    prm.crop2_enable = 0;
+    prm.rgb_offset = field_offset(*input, "rgb");
+    const int n = (int)(input->width * input->height);
+    std::vector<float> vox((size_t)n * 3);
+    std::vector<uint32_t> rgb((size_t)n);
+    int nc = 0, nv = 0;
+    if (cd_crop_voxel(ctx, input->data.data(), input->point_step, n, &prm, vox.data(), rgb.data(), n, &nc, &nv) != CD_OK) return;
+    std::vector<pclhip::PointXYZ> pts((size_t)nv);
+    for (int i = 0; i < nv; ++i) pts[(size_t)i] = pclhip::PointXYZ(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
+    std::vector<int32_t> inl((size_t)std::max(nv, 1));
+    float coeff[4] = {0, 0, 0, 0};
+    int ni = 0, it = 0;
+    const int st = cd_segment_plane(ctx, pts.data(), sizeof(pclhip::PointXYZ), nv, &prm, coeff, inl.data(), nv, &ni, &it);
+    pcl_msgs::ModelCoefficients ros_coefficients;
+    ros_coefficients.header = input->header;
+    if (st == CD_OK) ros_coefficients.values.assign(coeff, coeff + 4);
+    coef_pub.publish(ros_coefficients);
+    // ExtractIndices(negative=invert): x,y,z,rgb records of the kept voxel centroids
+    std::vector<char> is_inl((size_t)std::max(nv, 1), 0);
+    for (int k = 0; k < ni; ++k) is_inl[(size_t)inl[(size_t)k]] = 1;
+    sensor_msgs::PointCloud2 out;
+    out.header = input->header;
+    out.height = 1;
+    out.is_dense = true;
+    out.is_bigendian = false;
+    out.fields.resize(4);
+    const char* names[4] = {"x", "y", "z", "rgb"};
+    for (int k = 0; k < 4; ++k) { out.fields[k].name = names[k]; out.fields[k].offset = 4 * k; out.fields[k].datatype = sensor_msgs::PointField::FLOAT32; out.fields[k].count = 1; }
+    out.point_step = 16;
+    for (int i = 0; i < nv; ++i) {
+        if ((is_inl[(size_t)i] != 0) == invert) continue;
+        const size_t o = out.data.size();
+        out.data.resize(o + 16);
+        std::memcpy(&out.data[o], &vox[3 * (size_t)i], 12);
+        std::memcpy(&out.data[o + 12], &rgb[(size_t)i], 4);
+    }
+    out.width = (uint32_t)(out.data.size() / 16);
+    out.row_step = out.width * 16;
+    pcl_pub.publish(out);
+}
+
+int main(int argc, char** argv) {
+    ros::init(argc, argv, "ground_plane_segmentation");
+    ros::NodeHandle nh("~");
+    nh.param<bool>("invert", invert, true);
+    nh.param<double>("voxel_size", voxel_size, 0.01);
+    nh.param<double>("distance_threshold", distance_threshold, 0.01);
+    nh.param<std::string>("input", input_topic, "/camera/depth/color/points");
+    nh.param<std::string>("output", output_topic, "/ground_plane_segmentation/points");
+    nh.param<std::string>("plane_coefficients", coefficients_topic, "/ground_plane_segmentation/coefficients");
+    ros::Subscriber sub = nh.subscribe(input_topic, 1, callback);
+    pcl_pub = nh.advertise<sensor_msgs::PointCloud2>(output_topic, 1);
+    coef_pub = nh.advertise<pcl_msgs::ModelCoefficients>(coefficients_topic, 1);
+    ros::spin();
+}
+#else
+int main() { return 0; }   // ROS is not available in this build environment
+#endif

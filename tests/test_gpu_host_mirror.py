@@ -1,0 +1,63 @@
+"""The C++ host mirror (perception_amd/cpp/pcl_compat.hpp): the bodies of the reference's
+callbacks, written with pclhip:: classes where the reference uses pcl:: ones, produce what the
+oracle produces for the same frame (driver: perception_amd/cpp/cuboid_driver.cpp)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from perception_amd import capi, templates
+
+pytestmark = pytest.mark.gpu
+CPP = os.path.join(ROOT, "perception_amd", "cpp")
+
+
+def _run(mode, frame, tmp_path):
+    subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
+    fpath, tpath = str(tmp_path / "frame.bin"), str(tmp_path / "template.pcd")
+    frame.astype(np.float32).tofile(fpath)
+    open(tpath, "wb").write(templates.template_pcd_bytes(**templates.DEFAULT_TEMPLATE))
+    out = subprocess.run([os.path.join(CPP, "cuboid_driver"), "--frame", fpath, "--template", tpath, "--mode", mode],
+                         check=True, capture_output=True, text=True, timeout=120).stdout
+    return [ln.split() for ln in out.strip().splitlines()]
+
+
+def _hexes(tokens):
+    return [float.fromhex(t) for t in tokens]
+
+
+def test_opd_callback_body(O, template, frames4, tmp_path):
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    lines = _run("opd", frames4[1], tmp_path)
+    o = O.process_frame(frames4[1], prm, template, want_clouds=True)
+    ro = o["result"]
+    d = {ln[0]: ln[1:] for ln in lines if ln[0] in ("voxels", "plane_inliers", "objects", "clusters", "coefficients", "argmin")}
+    assert int(d["voxels"][0]) == ro.n_voxels and int(d["plane_inliers"][0]) == ro.n_plane
+    assert int(d["clusters"][0]) == ro.n_clusters
+    assert _hexes(d["coefficients"]) == [float(x) for x in ro.plane]
+    cl = [ln for ln in lines if ln[0] == "cluster"]
+    Ts = [ln for ln in lines if ln[0] == "T"]
+    assert len(cl) == ro.n_clusters
+    for k, (c, T) in enumerate(zip(cl, Ts)):
+        r = ro.clusters[k]
+        assert (int(c[2]), int(c[4]), int(c[6]), int(c[8])) == (r.size, r.iterations, r.converged, r.accepted)
+        assert float.fromhex(c[10]) == r.fitness
+        assert _hexes(T[1:]) == [float(x) for x in r.T]
+    diffs = [abs(ro.clusters[k].size - len(template)) for k in range(ro.n_clusters)]
+    assert int(d["argmin"][0]) == int(np.argmin(diffs))
+
+
+def test_gps_plus_icp_callback_bodies(O, template, frames4, tmp_path):
+    prm = capi.default_params()
+    prm.cluster_enable = 0
+    prm.crop2_enable = 0
+    lines = _run("gps", frames4[0], tmp_path)
+    ro = O.process_frame(frames4[0], prm, template)["result"]
+    icp = [ln for ln in lines if ln[0] == "icp"][0]
+    T = [ln for ln in lines if ln[0] == "T"][0]
+    r = ro.clusters[0]
+    assert (int(icp[2]), int(icp[4]), int(icp[6])) == (r.size, r.iterations, r.converged)
+    assert _hexes(T[1:]) == [float(x) for x in r.T]
