@@ -24,6 +24,7 @@ constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses 
 constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
 constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
 constexpr int ICP_SUB = 64;                // template run length that carries one pruning box
+constexpr int ICP_QSLICE = 512;            // max ICP source points (queries) per work item / workgroup
 
 // Per-frame scalars that live on the device and are mirrored to pinned host memory.
 struct FrameState {
@@ -59,6 +60,7 @@ struct IcpCluster {        // static description of one ICP problem (host-built)
 
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity
     float Tfinal[16];
+    float T[16];           // transformation_ of the current iteration
     double prev_mse;
     int32_t iters;
     int32_t done;

@@ -47,6 +47,7 @@ struct cd_context {
     // templates
     float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
+    float* d_d2 = nullptr;                                        // its squared distance
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
     // ICP
@@ -256,11 +257,16 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     c->timing.icp_kernel_ms = 0.f;
     if (pair_tests) *pair_tests = 0;
     if (ncl <= 0) return CD_OK;
+    // queries per workgroup: 512 when the batch fills the chip, smaller slices (more workgroups) otherwise
+    long long qtot = 0;
+    for (int k = 0; k < ncl; ++k) qtot += c->h_cl[k].n;
+    int qslice = (int)((qtot / 512 + 15) / 16 * 16);
+    qslice = std::max(64, std::min(ICP_QSLICE, qslice));
     int nwork = 0;
     for (int k = 0; k < ncl; ++k) {
         IcpCluster& cl = c->h_cl[k];
         cl.tile0 = nwork;
-        const int tiles = cl.n >= 3 && cl.tpl_m > 0 ? (cl.n + BLOCK - 1) / BLOCK : 0;
+        const int tiles = cl.n >= 3 && cl.tpl_m > 0 ? (cl.n + qslice - 1) / qslice : 0;
         if (nwork + tiles > c->work_cap) return fail(c, CD_ERR_CAPACITY, "ICP work list overflow");
         for (int t = 0; t < tiles; ++t) c->h_work[nwork++] = IcpWork{k, t};
         for (int s = 0; s < 2; ++s) {
@@ -290,7 +296,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int group = 16;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, ip);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, ncl, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, ip);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
@@ -299,7 +305,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
-    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src0, c->d_nn);
+    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src0, c->d_nn, c->d_d2, qslice);
     HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -505,7 +511,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -548,9 +554,9 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
-    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess;
+    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess;
     const size_t ncl = F * KICP;
-    c->work_cap = (int)(F * (N / BLOCK + KICP + 1));
+    c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;

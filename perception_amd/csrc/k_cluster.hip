@@ -70,10 +70,19 @@ __device__ __forceinline__ void uf_union(int* par, int a, int b) {
     }
 }
 
+// Cheap find for the hot loop: plain (L1-cacheable) loads, no writes.  A stale value is always
+// a past parent, i.e. still an ancestor-or-self, so a stale "root" only makes the CAS below fail,
+// after which the slow path re-reads with agent-scope atomics.
+__device__ __forceinline__ int uf_find_cached(const int* par, int x) {
+    int p = par[x];
+    while (p != x) { x = p; p = par[x]; }
+    return x;
+}
+
 __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict__ obj, int N,
                                                         const FrameState* __restrict__ fs, float inv_cell, float r2,
                                                         const int* __restrict__ head, const int* __restrict__ next,
-                                                        int* __restrict__ parent) {
+                                                        int* parent) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
     const size_t fbase = (size_t)f * N;
@@ -85,6 +94,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
         const float4 p = P[i];
         int cx, cy, cz;
         cell_of(p, fs[f].origin, inv_cell, cx, cy, cz);
+        int ri = uf_find_cached(par, i);   // root of i, kept in a register across its neighbours
         for (int a = -1; a <= 1; ++a)
             for (int b = -1; b <= 1; ++b)
                 for (int c = -1; c <= 1; ++c) {
@@ -92,11 +102,22 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
                     while (j >= 0) {
                         if (j < i) {
                             const float4 q = P[j];
-                            if (dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) uf_union(par, i, j);
+                            if (dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+                                int rj = uf_find_cached(par, j);
+                                while (ri != rj) {
+                                    const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
+                                    const int old = atomicCAS(par + hi, hi, lo);   // link the larger root under the smaller
+                                    if (old == hi) { ri = lo; rj = lo; break; }
+                                    ri = uf_find(par, old);                        // hi was no root any more: re-read coherently
+                                    rj = uf_find(par, lo);
+                                }
+                                ri = ri < rj ? ri : rj;
+                            }
                         }
                         j = nx[j];
                     }
                 }
+        if (ri != i) st_agent(par + i, ri);   // shortcut for later finds; i is not a root, so no CAS targets it
     }
 }
 

@@ -23,7 +23,6 @@
 
 namespace cd {
 
-constexpr int ICP_TILE = BLOCK;   // source points per work item (1 per lane)
 
 struct Rot { float c, s; };
 __device__ __forceinline__ Rot rot_mul(const Rot& a, const Rot& b) { return {a.c * b.c - a.s * b.s, a.c * b.s + a.s * b.c}; }
@@ -170,6 +169,29 @@ __device__ __forceinline__ void xform(const float* T, float x, float y, float z,
     oz = ((T[8] * x + T[9] * y) + T[10] * z) + T[11];
 }
 
+// ---------------------------------------------------------------------------------------
+// Exact nearest-neighbour search, "transposed": a wave owns ONE query at a time and its 64
+// lanes scan 64 template points per step out of LDS (one conflict-free ds_read_b128 per lane).
+//
+// The template is cut into runs of 64 consecutive points, each with an axis-aligned box
+// [lo,hi] (built at cd_set_template).  For a query q the bound
+//   e_a = max(lo_a - q_a, q_a - hi_a, 0),  lb = (e_x*e_x + e_y*e_y) + e_z*e_z
+// evaluated with the canonical association satisfies lb <= d2(q,p) for EVERY p in the run in
+// float arithmetic, because each step (rounded subtraction, square, rounded sum) is monotone
+// in |component|.  Lane l keeps the boxes of runs l and l+64 of the staged chunk in registers,
+// so ONE ballot per 64 runs yields the wave-uniform set of runs that can still hold a point
+// with d2 <= best; every other run is skipped without touching it.  This is pruning, not
+// approximation: no candidate that could improve on or tie the current best is dropped.
+// Seeding: best enters as nextafter(d2(q, seed)) with the previous iteration's neighbour as
+// seed; an ascending strict-< scan from that state still ends at the lowest index achieving
+// the global minimum (rule C5) - each lane keeps the first minimum of its own ascending
+// subsequence and the wave reduction takes the lexicographic minimum of (d2 bits, index).
+// ---------------------------------------------------------------------------------------
+constexpr int ICPT_THREADS = 1024;                 // 16 waves, 4 per SIMD
+constexpr int ICPT_WAVES = ICPT_THREADS / WAVE;
+constexpr int ICPT_TPL_LDS = 8192;                 // template points resident in LDS per pass (128 KiB)
+constexpr int ICPT_IMG = ICPT_TPL_LDS + ICP_SUB;   // + one pad run
+
 #ifdef CD_STATS
 __device__ unsigned long long g_icp_stats[4];
 extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
@@ -179,228 +201,304 @@ extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
 }
 #endif
 
-// Exact NN of (x,y,z) over the template, staged through LDS; every thread of the block calls it.
-//
-// Pruning is exact, not approximate.  The template is cut into runs of 64 consecutive points,
-// each with an axis-aligned box [lo,hi] (built at cd_set_template).  For a query q the bound
-//   e_a = max(lo_a - q_a, q_a - hi_a, 0),  lb = (e_x*e_x + e_y*e_y) + e_z*e_z
-// evaluated with the canonical association satisfies lb <= d2(q,p) for EVERY p in the run in
-// float arithmetic, because each step (rounded subtraction, square, rounded sum) is monotone in
-// |component|.  A run is skipped only when lb > best for all 64 lanes (wave vote), so no
-// candidate that could improve on or tie the current best is ever dropped.
-// Seeding: (best, bi) enter as (nextafter(d(q, seed)), seed); an ascending strict-< scan from
-// that state still ends at the lowest index achieving the global minimum (rule C5), and the run
-// holding the true NN can never be pruned since its lb <= d_min < best.
-__device__ __forceinline__ void nn_search(const float4* __restrict__ tpl, const float4* __restrict__ blo,
-                                          const float4* __restrict__ bhi, int m, float4* s_tpl, float4* s_lo,
-                                          float4* s_hi, float x, float y, float z, float& best, int& bi) {
-    for (int c0 = 0; c0 < m; c0 += ICP_TPL_CHUNK) {
-        const int cn = min(ICP_TPL_CHUNK, m - c0);
-        const int nsub = (cn + ICP_SUB - 1) / ICP_SUB;
-        __syncthreads();
-        for (int k = threadIdx.x; k < cn; k += BLOCK) s_tpl[k] = tpl[c0 + k];
-        if (threadIdx.x < nsub) {
-            s_lo[threadIdx.x] = blo[c0 / ICP_SUB + threadIdx.x];
-            s_hi[threadIdx.x] = bhi[c0 / ICP_SUB + threadIdx.x];
+__device__ __forceinline__ float next_up_nonneg(float d) { return __uint_as_float(__float_as_uint(d) + 1u); }
+__device__ __forceinline__ float seed_bound(float d0) { return d0 < 3.0e38f ? next_up_nonneg(d0) : __uint_as_float(0x7f800000u); }
+
+__device__ __forceinline__ float box_lb(const float4& L, const float4& H, float x, float y, float z) {
+    const float ex = fmaxf(fmaxf(L.x - x, x - H.x), 0.f);
+    const float ey = fmaxf(fmaxf(L.y - y, y - H.y), 0.f);
+    const float ez = fmaxf(fmaxf(L.z - z, z - H.z), 0.f);
+    return __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
+}
+
+// min over the 64 lanes of a non-negative float, by DPP row shifts + row broadcasts (no LDS).
+// Non-negative floats order like their bit patterns, so the reduction is an unsigned integer min.
+__device__ __forceinline__ float wave_min_f32_nonneg(float v) {
+    unsigned x = __float_as_uint(v);
+#define CD_DPP_MIN(ctrl, rowmask) x = min(x, (unsigned)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)x, ctrl, rowmask, 0xf, false));
+    CD_DPP_MIN(0x111, 0xf)   // row_shr:1
+    CD_DPP_MIN(0x112, 0xf)   // row_shr:2
+    CD_DPP_MIN(0x114, 0xf)   // row_shr:4
+    CD_DPP_MIN(0x118, 0xf)   // row_shr:8   -> lane 15 of every row holds the row minimum
+    CD_DPP_MIN(0x142, 0xa)   // row_bcast:15 into rows 1,3
+    CD_DPP_MIN(0x143, 0xc)   // row_bcast:31 into rows 2,3 -> lane 63 holds the wave minimum
+#undef CD_DPP_MIN
+    return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)x, 63));
+}
+
+// NN of every query of the block's slice (nq <= 1024): results to nn[] / d2buf[].
+// Wave w owns queries w, w+16, w+32, ...; lane k of the wave fetches query k's point, seed and
+// seed distance up front (one batched round of global loads per wave), then the wave walks its
+// queries with the point broadcast out of lane k by v_readlane (wave-uniform, lives in SGPRs).
+// use_prev: seeds are the previous launch's neighbours (nn[]); otherwise a coarse seed (best of
+// the first point of every run).  apply_T: queries are Tm * pts (fitness pass).
+__device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const float4* __restrict__ blo,
+                                         const float4* __restrict__ bhi, int m, float4* s_tpl, const float4* pts,
+                                         int nq, bool use_prev, bool coarse, bool apply_T, const float* Tm, int* nn, float* d2buf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int myq = wave + ICPT_WAVES * lane;          // the query this lane fetches / stores
+    const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;   // queries of this wave
+    float px = 0.f, py = 0.f, pz = 0.f, pbest = 0.f;
+    int pbi = 0;
+    if (lane < nk) {
+        const float4 p = pts[myq];
+        px = p.x; py = p.y; pz = p.z;
+        if (apply_T) xform(Tm, p.x, p.y, p.z, px, py, pz);
+        // seed = better of (previous launch's neighbour, best first-point-of-run).  The coarse scan is
+        // only worth its 114 tests while the cloud still moves a lot between launches.
+        pbest = 3.402823466e38f;
+        if (use_prev) {
+            pbi = nn[myq];
+            const float4 q0 = tpl[pbi];
+            pbest = dist2(px, py, pz, q0.x, q0.y, q0.z);
         }
-        __syncthreads();
-        for (int s = 0; s < nsub; ++s) {
-            const float4 L = s_lo[s], H = s_hi[s];
-            const float ex = fmaxf(fmaxf(L.x - x, x - H.x), 0.f);
-            const float ey = fmaxf(fmaxf(L.y - y, y - H.y), 0.f);
-            const float ez = fmaxf(fmaxf(L.z - z, z - H.z), 0.f);
-            const float lb = __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
-#ifdef CD_STATS
-            if ((threadIdx.x & 63) == 0) atomicAdd(&g_icp_stats[0], 1ull);
-            { const unsigned long long need = __popcll(__ballot(lb <= best)); if ((threadIdx.x & 63) == 0 && need) { atomicAdd(&g_icp_stats[1], 1ull); atomicAdd(&g_icp_stats[2], need); } }
-#endif
-            if (__any(lb <= best)) {                       // wave-uniform; inactive lanes carry best = -1
-                const int j0 = s * ICP_SUB, j1 = min(j0 + ICP_SUB, cn);
-#pragma unroll 8
-                for (int j = j0; j < j1; ++j) {
-                    const float4 t = s_tpl[j];
-                    const float d = dist2(x, y, z, t.x, t.y, t.z);
-                    if (d < best) { best = d; bi = c0 + j; }   // strict: lowest index wins ties (C5)
-                }
+        if (coarse) {
+            for (int j = 0; j < m; j += ICP_SUB) {
+                const float4 t = tpl[j];
+                const float d = dist2(px, py, pz, t.x, t.y, t.z);
+                if (d < pbest) { pbest = d; pbi = j; }
             }
         }
+        pbest = seed_bound(pbest);
+    }
+    for (int c0 = 0; c0 < m; c0 += ICPT_TPL_LDS) {
+        const int cn = min(ICPT_TPL_LDS, m - c0);
+        const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
+        __syncthreads();
+        // image = the chunk, its last run padded to 64 points, plus one whole pad run; pad points sit at
+        // +inf so their distance is +inf and they can never win (removes every bounds predicate below)
+        const float inf = __uint_as_float(0x7f800000u);
+        for (int k = threadIdx.x; k < (nruns + 1) * ICP_SUB; k += ICPT_THREADS)
+            s_tpl[k] = k < cn ? tpl[c0 + k] : make_float4(inf, inf, inf, 0.f);
+        // boxes of runs `lane` and `lane+64` of this chunk; an absent run gets an unreachable box
+        float4 L0 = make_float4(inf, inf, inf, 0.f), H0 = L0, L1 = L0, H1 = L0;
+        if (lane < nruns) { L0 = blo[c0 / ICP_SUB + lane]; H0 = bhi[c0 / ICP_SUB + lane]; }
+        if (lane + 64 < nruns) { L1 = blo[c0 / ICP_SUB + lane + 64]; H1 = bhi[c0 / ICP_SUB + lane + 64]; }
+        __syncthreads();
+        for (int k = 0; k < nk; ++k) {
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), k));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), k));
+            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), k));
+            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pbest), k));
+            const int bi = __builtin_amdgcn_readlane(pbi, k);
+            unsigned long long m0 = __ballot(box_lb(L0, H0, x, y, z) <= best);
+            unsigned long long m1 = __ballot(box_lb(L1, H1, x, y, z) <= best);
+#ifdef CD_STATS
+            if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+            float lbest = best;
+            int lbi = bi;
+            // visit the surviving runs in ascending order, four LDS reads in flight at a time
+            const int pad = nruns;   // index of the all-inf pad run
+#define CD_VISIT4(mask, base)                                                                   \
+            while (mask) {                                                                      \
+                const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;         \
+                const int r1 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
+                const int r2 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
+                const int r3 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
+                const float4 t0 = s_tpl[r0 * ICP_SUB + lane], t1 = s_tpl[r1 * ICP_SUB + lane];  \
+                const float4 t2 = s_tpl[r2 * ICP_SUB + lane], t3 = s_tpl[r3 * ICP_SUB + lane];  \
+                const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                              \
+                const float d1 = dist2(x, y, z, t1.x, t1.y, t1.z);                              \
+                const float d2 = dist2(x, y, z, t2.x, t2.y, t2.z);                              \
+                const float d3 = dist2(x, y, z, t3.x, t3.y, t3.z);                              \
+                if (d0 < lbest) { lbest = d0; lbi = c0 + r0 * ICP_SUB + lane; }                 \
+                if (d1 < lbest) { lbest = d1; lbi = c0 + r1 * ICP_SUB + lane; }                 \
+                if (d2 < lbest) { lbest = d2; lbi = c0 + r2 * ICP_SUB + lane; }                 \
+                if (d3 < lbest) { lbest = d3; lbi = c0 + r3 * ICP_SUB + lane; }                 \
+            }
+            CD_VISIT4(m0, 0)
+            CD_VISIT4(m1, 64)
+#undef CD_VISIT4
+            // lexicographic (d2, index) minimum over the wave: min distance by DPP, then the lowest
+            // index among the lanes that hold it (almost always exactly one lane)
+            const float dmin = wave_min_f32_nonneg(lbest);
+            unsigned long long eq = __ballot(lbest == dmin);
+            int rbi = 0x7fffffff;
+            while (eq) {
+                const int l = __ffsll((long long)eq) - 1;
+                eq &= eq - 1;
+                rbi = min(rbi, __builtin_amdgcn_readlane(lbi, l));
+            }
+            if (lane == k) { pbest = dmin; pbi = rbi; }   // carried into the next chunk / stored below
+        }
+    }
+    if (lane < nk) {
+        nn[myq] = pbi;
+        d2buf[myq] = pbest;
     }
 }
 
-
-// seed for a search that has no previous neighbour: best over the first point of every run
-__device__ __forceinline__ void nn_seed_coarse(const float4* __restrict__ tpl, int m, float x, float y, float z,
-                                               float& best, int& bi) {
-    best = 3.402823466e38f;
-    bi = 0;
-    for (int j = 0; j < m; j += ICP_SUB) {
-        const float4 t = tpl[j];
-        const float d = dist2(x, y, z, t.x, t.y, t.z);
-        if (d < best) { best = d; bi = j; }
-    }
-}
-__device__ __forceinline__ float next_up_nonneg(float d) { return __uint_as_float(__float_as_uint(d) + 1u); }
-
-__global__ void __launch_bounds__(BLOCK) k_icp_iter(int it, const IcpWork* __restrict__ work,
-                                                    const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
-                                                    unsigned long long* __restrict__ acc, const float4* __restrict__ tpl,
-                                                    const float4* __restrict__ tlo, const float4* __restrict__ thi,
-                                                    float4* __restrict__ src, int* __restrict__ nn, IcpParams prm) {
-    __shared__ float4 s_tpl[ICP_TPL_CHUNK];
-    __shared__ float4 s_lo[ICP_TPL_CHUNK / ICP_SUB], s_hi[ICP_TPL_CHUNK / ICP_SUB];
-    __shared__ float s_T[16];
-    __shared__ int s_done;
-    const IcpWork wk = work[blockIdx.x];
-    const IcpCluster c = cl[wk.cluster];
-    const IcpState* sin = st + (size_t)wk.cluster * 2 + (it & 1);
-    IcpState* sout = st + (size_t)wk.cluster * 2 + ((it + 1) & 1);
-    const int lane = threadIdx.x & 63;
-    if (sin->done) {
-        if (wk.tile == 0 && threadIdx.x == 0) *sout = *sin;
-        return;
-    }
-    if (threadIdx.x == 0) {
-        IcpState so = *sin;
+// One thread per cluster: TransformationEstimationSVD + final_transformation_ update +
+// DefaultConvergenceCriteria for launch `it`, from the moments launch it-1 accumulated.
+// Writes the state slot k_icp_iter(it) consumes, keeps the `done` flag in both parity slots and
+// clears the moment buffer launch it+1 will accumulate into.
+__global__ void __launch_bounds__(WAVE) k_icp_solve(int it, int ncl, const IcpCluster* __restrict__ cl,
+                                                    IcpState* __restrict__ st, unsigned long long* __restrict__ acc,
+                                                    IcpParams prm) {
+    const int k = blockIdx.x * WAVE + threadIdx.x;
+    if (k >= ncl) return;
+    const IcpState* sin = st + (size_t)k * 2 + (it & 1);
+    IcpState* sout = st + (size_t)k * 2 + ((it + 1) & 1);
+    if (sin->done) { *sout = *sin; return; }
+    IcpState so = *sin;
+    if (it > 0) {
+        const IcpCluster c = cl[k];
+        const unsigned long long* A = acc + ((size_t)k * 3 + (it - 1) % 3) * 16;
+        float T[16];
+        umeyama_from_moments(A, c.n, T);
+        // final_transformation_ = transformation_ * final_transformation_
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                so.Tfinal[4 * i + j] = ((T[4 * i] * sin->Tfinal[j] + T[4 * i + 1] * sin->Tfinal[4 + j]) +
+                                        T[4 * i + 2] * sin->Tfinal[8 + j]) + T[4 * i + 3] * sin->Tfinal[12 + j];
+        so.iters = sin->iters + 1;
         int done = 0;
-        if (it > 0) {
-            const unsigned long long* A = acc + ((size_t)wk.cluster * 3 + (it - 1) % 3) * 16;
-            float T[16];
-            umeyama_from_moments(A, c.n, T);
-            // final_transformation_ = transformation_ * final_transformation_
-            for (int i = 0; i < 4; ++i)
-                for (int j = 0; j < 4; ++j)
-                    so.Tfinal[4 * i + j] = ((T[4 * i] * sin->Tfinal[j] + T[4 * i + 1] * sin->Tfinal[4 + j]) +
-                                            T[4 * i + 2] * sin->Tfinal[8 + j]) + T[4 * i + 3] * sin->Tfinal[12 + j];
-            so.iters = sin->iters + 1;
-            // DefaultConvergenceCriteria::hasConverged
-            if (so.iters >= prm.max_iter) {
+        // DefaultConvergenceCriteria::hasConverged
+        if (so.iters >= prm.max_iter) {
+            done = 1;
+        } else {
+            const double cos_angle = 0.5 * (double)(((T[0] + T[5]) + T[10]) - 1.0f);
+            const double translation_sqr = (double)((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
+            if (cos_angle >= prm.rot_thr && translation_sqr <= prm.trans_eps) {
                 done = 1;
             } else {
-                const double cos_angle = 0.5 * (double)(((T[0] + T[5]) + T[10]) - 1.0f);
-                const double translation_sqr = (double)((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
-                if (cos_angle >= prm.rot_thr && translation_sqr <= prm.trans_eps) {
-                    done = 1;
-                } else {
-                    const double mse = unfix(A[15], FIX_SHIFT_D2) / (double)c.n;
-                    if (fabs(mse - sin->prev_mse) < prm.abs_mse) done = 1;
-                    else if (fabs(mse - sin->prev_mse) / sin->prev_mse < prm.rel_mse) done = 1;
-                    so.prev_mse = mse;
-                }
+                const double mse = unfix(A[15], FIX_SHIFT_D2) / (double)c.n;
+                if (fabs(mse - sin->prev_mse) < prm.abs_mse) done = 1;
+                else if (fabs(mse - sin->prev_mse) / sin->prev_mse < prm.rel_mse) done = 1;
+                so.prev_mse = mse;
             }
-            so.done = done;
-            so.converged = done;
-            for (int i = 0; i < 16; ++i) s_T[i] = T[i];
         }
-        s_done = done;
-        if (wk.tile == 0) *sout = so;
+        so.done = done;
+        so.converged = done;
+        for (int i = 0; i < 16; ++i) so.T[i] = T[i];
     }
-    if (wk.tile == 0 && threadIdx.x >= 64 && threadIdx.x < 80)
-        acc[((size_t)wk.cluster * 3 + (it + 1) % 3) * 16 + (threadIdx.x - 64)] = 0ull;
-    __syncthreads();
-    const int i = wk.tile * ICP_TILE + threadIdx.x;
-    const bool active = i < c.n;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (active) {
-        const float4 p = src[c.src_off + i];
-        x = p.x; y = p.y; z = p.z;
-        if (it > 0) {
-            float T[16];
+    *sout = so;
+    unsigned long long* Z = acc + ((size_t)k * 3 + (it + 1) % 3) * 16;
+    for (int i = 0; i < 16; ++i) Z[i] = 0ull;
+}
+
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, const IcpWork* __restrict__ work,
+                                                           const IcpCluster* __restrict__ cl, const IcpState* __restrict__ st,
+                                                           unsigned long long* __restrict__ acc,
+                                                           const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                           const float4* __restrict__ thi, float4* src, int* nn,
+                                                           float* d2buf, int qslice) {
+    __shared__ float4 s_tpl[ICPT_IMG];
+    const IcpWork wk = work[blockIdx.x];
+    const IcpCluster c = cl[wk.cluster];
+    const IcpState* sin = st + (size_t)wk.cluster * 2 + (it & 1);          // state before this launch
+    const IcpState* snow = st + (size_t)wk.cluster * 2 + ((it + 1) & 1);   // written by k_icp_solve(it)
+    const int lane = threadIdx.x & 63;
+    if (sin->done) return;
+    const int done_now = snow->done;
+    const int q0 = wk.tile * qslice;
+    const int nq = min(qslice, c.n - q0);
+    float4* pts = src + c.src_off + q0;
+    int* nnq = nn + c.src_off + q0;
+    float* d2q = d2buf + c.src_off + q0;
+    if (it > 0) {   // X <- T * X, in place
+        float T[12];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) T[k] = s_T[k];
+        for (int k = 0; k < 12; ++k) T[k] = snow->T[k];
+        for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) {
+            const float4 p = pts[i];
             float ox, oy, oz;
-            xform(T, x, y, z, ox, oy, oz);
-            x = ox; y = oy; z = oz;
-            src[c.src_off + i] = make_float4(x, y, z, p.w);
+            xform(T, p.x, p.y, p.z, ox, oy, oz);
+            pts[i] = make_float4(ox, oy, oz, p.w);
         }
     }
-    if (s_done) return;
-    float best = -1.0f;   // inactive lanes never vote for a run and never update
-    int bi = 0;
-    const float4* tp = tpl + c.tpl_off;
-    if (active) {
-        if (it > 0) {
-            bi = nn[c.src_off + i];                    // previous iteration's neighbour
-            const float4 q0 = tp[bi];
-            best = dist2(x, y, z, q0.x, q0.y, q0.z);
-        } else {
-            nn_seed_coarse(tp, c.tpl_m, x, y, z, best, bi);
+    if (done_now) return;
+    __syncthreads();   // the transformed points are read by other waves below
+    static_assert(ICP_QSLICE <= ICPT_THREADS && 16 * ICP_QSLICE * 8 <= ICPT_TPL_LDS * 16, "slice must fit the block / LDS scratch");
+    nn_slice(tpl + c.tpl_off, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, pts, nq, it > 0, it < 6, false,
+             nullptr, nnq, d2q);
+    __syncthreads();
+    // 16 fixed-point moments of the correspondences of this slice: per-point terms go to LDS
+    // (term-major, conflict-free; the template image is dead by now), wave k then sums term k.
+    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_tpl);   // 16 x ICP_QSLICE x 8 B = 64 KiB
+    if (threadIdx.x < ICP_QSLICE) {
+        const int i = threadIdx.x;
+        unsigned long long S[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) S[k] = 0ull;
+        if (i < nq) {
+            const float4 p = pts[i];
+            const float4 q = tpl[c.tpl_off + nnq[i]];
+            const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+            }
+            S[15] = (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
         }
-        best = best < 3.0e38f ? next_up_nonneg(best) : __uint_as_float(0x7f800000u);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) scratch[k * ICP_QSLICE + i] = S[k];
     }
-    nn_search(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, s_lo, s_hi, x, y, z, best, bi);
-    if (active) nn[c.src_off + i] = bi;
-    unsigned long long S[16];
+    __syncthreads();
+    {
+        const int k = threadIdx.x >> 6;   // 16 waves <-> 16 moments
+        unsigned long long t = 0ull;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) S[k] = 0ull;
-    if (active) {
-        const float4 q = tpl[c.tpl_off + bi];
-        const float pv[3] = {x, y, z}, qv[3] = {q.x, q.y, q.z};
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
-            S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
-#pragma unroll
-            for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
-        }
-        S[15] = (unsigned long long)fixq(best, FIX_SHIFT_D2);
-    }
-    unsigned long long* A = acc + ((size_t)wk.cluster * 3 + it % 3) * 16;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const unsigned long long t = wave_sum_u64(S[k]);
-        if (lane == 0) atomicAdd(&A[k], t);
+        for (int j = 0; j < ICP_QSLICE / 64; ++j) t += scratch[k * ICP_QSLICE + j * 64 + lane];
+        t = wave_sum_u64(t);
+        if (lane == 0) atomicAdd(&acc[((size_t)wk.cluster * 3 + it % 3) * 16 + k], t);
     }
 }
 
 // getFitnessScore(): mean squared NN distance of T_final * (original source)
-__global__ void __launch_bounds__(BLOCK) k_icp_fitness(const IcpWork* __restrict__ work, const IcpCluster* __restrict__ cl,
-                                                       const IcpState* __restrict__ st, int parity,
-                                                       unsigned long long* __restrict__ accf,
-                                                       const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                       const float4* __restrict__ thi, const float4* __restrict__ src0,
-                                                       const int* __restrict__ nn) {
-    __shared__ float4 s_tpl[ICP_TPL_CHUNK];
-    __shared__ float4 s_lo[ICP_TPL_CHUNK / ICP_SUB], s_hi[ICP_TPL_CHUNK / ICP_SUB];
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __restrict__ work,
+                                                              const IcpCluster* __restrict__ cl,
+                                                              const IcpState* __restrict__ st, int parity,
+                                                              unsigned long long* __restrict__ accf,
+                                                              const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                              const float4* __restrict__ thi, const float4* src0, int* nn,
+                                                              float* d2buf, int qslice) {
+    __shared__ float4 s_tpl[ICPT_IMG];
+    __shared__ unsigned long long s_acc;
+    __shared__ float s_T[16];
     const IcpWork wk = work[blockIdx.x];
     const IcpCluster c = cl[wk.cluster];
     const IcpState* s = st + (size_t)wk.cluster * 2 + parity;
     if (s->status != CD_OK) return;
-    const int i = wk.tile * ICP_TILE + threadIdx.x;
-    const bool active = i < c.n;
-    float x = 0.f, y = 0.f, z = 0.f;
-    if (active) {
-        const float4 p = src0[c.src_off + i];
-        float T[12];
+    if (threadIdx.x < 16) s_T[threadIdx.x] = s->Tfinal[threadIdx.x];
+    if (threadIdx.x == 16) s_acc = 0ull;
+    __syncthreads();
+    float T[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) T[k] = s->Tfinal[k];
-        xform(T, p.x, p.y, p.z, x, y, z);
+    for (int k = 0; k < 12; ++k) T[k] = s_T[k];
+    const int q0 = wk.tile * qslice;
+    const int nq = min(qslice, c.n - q0);
+    int* nnq = nn + c.src_off + q0;
+    float* d2q = d2buf + c.src_off + q0;
+    nn_slice(tpl + c.tpl_off, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, src0 + c.src_off + q0, nq,
+             true, false, true, T, nnq, d2q);
+    __syncthreads();
+    unsigned long long v = 0ull;
+    for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) v += (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
+    if ((threadIdx.x & ~63) < nq) {
+        const unsigned long long t = wave_sum_u64(v);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&s_acc, t);
     }
-    float best = -1.0f;
-    int bi = 0;
-    const float4* tp = tpl + c.tpl_off;
-    if (active) {
-        bi = nn[c.src_off + i];                        // last iteration's neighbour as the seed
-        const float4 q0 = tp[bi];
-        best = dist2(x, y, z, q0.x, q0.y, q0.z);
-        best = best < 3.0e38f ? next_up_nonneg(best) : __uint_as_float(0x7f800000u);
-    }
-    nn_search(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, s_lo, s_hi, x, y, z, best, bi);
-    const unsigned long long v = active ? (unsigned long long)fixq(best, FIX_SHIFT_D2) : 0ull;
-    const unsigned long long t = wave_sum_u64(v);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&accf[wk.cluster], t);
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&accf[wk.cluster], s_acc);
 }
 
-void launch_icp_iter(hipStream_t s, int it, int n_work, const IcpWork* work, const IcpCluster* cl, IcpState* st,
+void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                      unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
-                     int* nn, IcpParams prm) {
+                     int* nn, float* d2buf, int qslice, IcpParams prm) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_iter, dim3(n_work), dim3(BLOCK), 0, s, it, work, cl, st, acc, tpl, tlo, thi, src, nn, prm);
+    hipLaunchKernelGGL(k_icp_solve, dim3((ncl + WAVE - 1) / WAVE), dim3(WAVE), 0, s, it, ncl, cl, st, acc, prm);
+    hipLaunchKernelGGL(k_icp_iter, dim3(n_work), dim3(ICPT_THREADS), 0, s, it, work, cl, st, acc, tpl, tlo, thi, src, nn, d2buf, qslice);
 }
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
-                        const float4* src0, const int* nn) {
+                        const float4* src0, int* nn, float* d2buf, int qslice) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(BLOCK), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, src0, nn);
+    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(ICPT_THREADS), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, src0, nn, d2buf, qslice);
 }
 
 }  // namespace cd

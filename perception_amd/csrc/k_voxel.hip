@@ -236,6 +236,8 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
                                                           const FrameState* __restrict__ fs,
                                                           const int* __restrict__ tile_off, float4* __restrict__ vox) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ float4 s_p[TILE];   // the tile's points in sorted order (32 KiB): the scattered gather is
+                                   // done once, by all lanes; the sequential per-voxel sums then read LDS
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * TILE >= n) return;
@@ -247,7 +249,9 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     int wtot = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
+        const int e = base + j * WAVE + lane;
+        if (e < n) s_p[e - tile * TILE] = cpt[fbase + v[e]];
+        bal[j] = __ballot(is_head(k, e, n));
         wtot += __popcll(bal[j]);
     }
     if (lane == 0) s_cnt[w] = wtot;
@@ -263,8 +267,9 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
             const uint32_t key = k[e];
             float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
             int cnt = 0;
+            const int tile_end = tile * TILE + TILE;
             do {
-                const float4 p = cpt[fbase + v[e]];
+                const float4 p = e < tile_end ? s_p[e - tile * TILE] : cpt[fbase + v[e]];   // runs may spill into the next tile
                 sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z);
                 if (rgb_on) {
                     const uint32_t u = __float_as_uint(p.w);

@@ -1,0 +1,10 @@
+import csv, sys, glob, collections
+f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]
+agg = collections.defaultdict(lambda: collections.defaultdict(float))
+cnt = collections.Counter()
+for r in csv.DictReader(open(f)):
+    name = r['Kernel_Name'].split('(')[0].replace('cd::', '')
+    agg[name][r['Counter_Name']] += float(r['Counter_Value'])
+    cnt[(name, r['Counter_Name'])] += 1
+for name in sorted(agg, key=lambda n: -agg[n].get('SQ_WAVE_CYCLES', agg[n].get('SQ_WAVES', 0))):
+    print(name, {k: ('%.4g' % v) for k, v in sorted(agg[name].items())}, 'dispatches', max(cnt[(name, k)] for k in agg[name]))

@@ -15,6 +15,6 @@ lib.cd_debug_icp_stats(out, 1)
 t = ctx.timing()
 tests, proc, lanes = out[0], out[1], out[2]
 print('launches', t.icp_kernel_launches, 'icp ms', t.icp_kernel_ms)
-print('box tests (wave)', tests, 'runs processed (wave)', proc, 'frac', proc / max(tests, 1), 'avg lanes needing a processed run', lanes / max(proc, 1))
+print("runs offered", tests, "runs visited", proc, "queries", lanes, "visited per query", proc / max(lanes, 1), "frac", proc / max(tests, 1))
 its = [r.clusters[k].iterations for r in res for k in range(r.n_clusters)]
 print('iters', its)
