@@ -156,6 +156,15 @@ def main():
         avg_launch_ms = icp_ms / max(icp_launches, 1)
         per_launch_bytes = icp_balg / max(icp_launches / args.steps, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9
+        # HBM bytes per k_icp_iter launch from the PMC passes (profiles/r01_pmc_traffic.json: separate
+        # FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 x2 FETCH correction applied)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            if F == 256 and N == 307200:
+                traffic = pmc["kernels"]["k_icp_iter"]["hbm_bytes_per_dispatch"]
+        except (OSError, KeyError, ValueError):
+            pass
         out = {
             "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -166,7 +175,7 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
             "roofline": {"kernel": "k_icp_iter", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "note": "dominant kernel by time; its pair loop is f32-VALU bound, not HBM bound - see roofline_valu"},

@@ -589,17 +589,64 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         off = c->tpl_used;
         c->tpl_used += m_pad;
     }
-    int st = upload_points(c, xyz, stride, m, c->d_tpl + off);
-    if (st) return st;
-    {   // axis-aligned box of every run of 64 consecutive template points (exact float min/max)
+    // Re-tile the template into compact patches of 64 points (k-d median splits whose left part is a
+    // multiple of 64): consecutive runs of 64 stored points then have small bounding boxes, which is
+    // what the exact pruning in k_icp_iter feeds on.  Each stored point keeps its ORIGINAL index in .w;
+    // the nearest-neighbour tie rule (lowest original index) is evaluated on that.
+    struct TP { float x, y, z; int oi; };
+    std::vector<TP> tp((size_t)m);
+    {
+        const char* b = (const char*)xyz;
+        for (int i = 0; i < m; ++i) {
+            float v[3];
+            std::memcpy(v, b + (size_t)i * stride, 12);
+            tp[(size_t)i] = TP{v[0], v[1], v[2], i};
+        }
+    }
+    {
+        std::vector<std::pair<int, int>> stack;   // [lo, hi)
+        stack.push_back({0, m});
+        while (!stack.empty()) {
+            const auto [lo, hi] = stack.back();
+            stack.pop_back();
+            const int n = hi - lo;
+            if (n <= ICP_SUB) {
+                std::sort(tp.begin() + lo, tp.begin() + hi, [](const TP& a, const TP& bb) { return a.oi < bb.oi; });
+                continue;
+            }
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int i = lo; i < hi; ++i) {
+                const float v[3] = {tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
+            }
+            int ax = 0;
+            if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+            if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+            int k = ((n / 2 + ICP_SUB - 1) / ICP_SUB) * ICP_SUB;
+            if (k >= n) k -= ICP_SUB;
+            auto key = [ax](const TP& t) { return ax == 0 ? t.x : (ax == 1 ? t.y : t.z); };
+            std::nth_element(tp.begin() + lo, tp.begin() + lo + k, tp.begin() + hi,
+                             [&](const TP& a, const TP& bb) { return key(a) < key(bb) || (key(a) == key(bb) && a.oi < bb.oi); });
+            stack.push_back({lo + k, hi});
+            stack.push_back({lo, lo + k});
+        }
+    }
+    {
+        std::vector<float4> dev((size_t)m);
+        for (int i = 0; i < m; ++i) {
+            float w;
+            std::memcpy(&w, &tp[(size_t)i].oi, 4);
+            dev[(size_t)i] = make_float4(tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z, w);
+        }
+        HIPCHK(c, hipMemcpy(c->d_tpl + off, dev.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice));
+    }
+    {   // axis-aligned box of every run of 64 consecutive STORED points (exact float min/max)
         const int nrun = m_pad / ICP_SUB;
         std::vector<float4> lo((size_t)nrun), hi((size_t)nrun);
-        const char* b = (const char*)xyz;
         for (int r = 0; r < nrun; ++r) {
             float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
             for (int i = r * ICP_SUB; i < std::min(m, (r + 1) * ICP_SUB); ++i) {
-                float v[3];
-                std::memcpy(v, b + (size_t)i * stride, 12);
+                const float v[3] = {tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z};
                 for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
             }
             lo[r] = make_float4(mn[0], mn[1], mn[2], 0.f);

@@ -239,7 +239,7 @@ __device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const f
     const int myq = wave + ICPT_WAVES * lane;          // the query this lane fetches / stores
     const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;   // queries of this wave
     float px = 0.f, py = 0.f, pz = 0.f, pbest = 0.f;
-    int pbi = 0;
+    int pbi = 0, poi = 0x7fffffff;   // stored position of the best point and its ORIGINAL template index
     if (lane < nk) {
         const float4 p = pts[myq];
         px = p.x; py = p.y; pz = p.z;
@@ -260,6 +260,7 @@ __device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const f
             }
         }
         pbest = seed_bound(pbest);
+        poi = __float_as_int(tpl[pbi].w);
     }
     for (int c0 = 0; c0 < m; c0 += ICPT_TPL_LDS) {
         const int cn = min(ICPT_TPL_LDS, m - c0);
@@ -269,7 +270,7 @@ __device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const f
         // +inf so their distance is +inf and they can never win (removes every bounds predicate below)
         const float inf = __uint_as_float(0x7f800000u);
         for (int k = threadIdx.x; k < (nruns + 1) * ICP_SUB; k += ICPT_THREADS)
-            s_tpl[k] = k < cn ? tpl[c0 + k] : make_float4(inf, inf, inf, 0.f);
+            s_tpl[k] = k < cn ? tpl[c0 + k] : make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
         // boxes of runs `lane` and `lane+64` of this chunk; an absent run gets an unreachable box
         float4 L0 = make_float4(inf, inf, inf, 0.f), H0 = L0, L1 = L0, H1 = L0;
         if (lane < nruns) { L0 = blo[c0 / ICP_SUB + lane]; H0 = bhi[c0 / ICP_SUB + lane]; }
@@ -281,46 +282,51 @@ __device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const f
             const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), k));
             const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pbest), k));
             const int bi = __builtin_amdgcn_readlane(pbi, k);
+            const int boi = __builtin_amdgcn_readlane(poi, k);
             unsigned long long m0 = __ballot(box_lb(L0, H0, x, y, z) <= best);
             unsigned long long m1 = __ballot(box_lb(L1, H1, x, y, z) <= best);
 #ifdef CD_STATS
             if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
             float lbest = best;
-            int lbi = bi;
-            // visit the surviving runs in ascending order, four LDS reads in flight at a time
-            const int pad = nruns;   // index of the all-inf pad run
-#define CD_VISIT4(mask, base)                                                                   \
+            int lbi = bi, loi = boi;
+            // Visit the surviving runs, two LDS reads in flight at a time.  The template is stored
+            // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
+            // order: the update is the lexicographic (d2, original index) comparison (rule C5).
+            const int pad = nruns;   // index of the all-inf pad run (its original index is INT_MAX)
+#define CD_TAKE(dd, tt, rr)                                                                     \
+            {                                                                                   \
+                const int oi_ = __float_as_int(tt.w);                                           \
+                const bool up_ = (dd < lbest) || (dd == lbest && oi_ < loi);                    \
+                lbest = up_ ? dd : lbest; lbi = up_ ? c0 + rr * ICP_SUB + lane : lbi; loi = up_ ? oi_ : loi; \
+            }
+#define CD_VISIT2(mask, base)                                                                   \
             while (mask) {                                                                      \
                 const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;         \
                 const int r1 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
-                const int r2 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
-                const int r3 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
                 const float4 t0 = s_tpl[r0 * ICP_SUB + lane], t1 = s_tpl[r1 * ICP_SUB + lane];  \
-                const float4 t2 = s_tpl[r2 * ICP_SUB + lane], t3 = s_tpl[r3 * ICP_SUB + lane];  \
                 const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                              \
                 const float d1 = dist2(x, y, z, t1.x, t1.y, t1.z);                              \
-                const float d2 = dist2(x, y, z, t2.x, t2.y, t2.z);                              \
-                const float d3 = dist2(x, y, z, t3.x, t3.y, t3.z);                              \
-                if (d0 < lbest) { lbest = d0; lbi = c0 + r0 * ICP_SUB + lane; }                 \
-                if (d1 < lbest) { lbest = d1; lbi = c0 + r1 * ICP_SUB + lane; }                 \
-                if (d2 < lbest) { lbest = d2; lbi = c0 + r2 * ICP_SUB + lane; }                 \
-                if (d3 < lbest) { lbest = d3; lbi = c0 + r3 * ICP_SUB + lane; }                 \
+                CD_TAKE(d0, t0, r0)                                                             \
+                CD_TAKE(d1, t1, r1)                                                             \
             }
-            CD_VISIT4(m0, 0)
-            CD_VISIT4(m1, 64)
-#undef CD_VISIT4
-            // lexicographic (d2, index) minimum over the wave: min distance by DPP, then the lowest
-            // index among the lanes that hold it (almost always exactly one lane)
+            CD_VISIT2(m0, 0)
+            CD_VISIT2(m1, 64)
+#undef CD_VISIT2
+#undef CD_TAKE
+            // lexicographic (d2, original index) minimum over the wave: min distance by DPP, then the
+            // lowest original index among the lanes that hold it (almost always exactly one lane)
             const float dmin = wave_min_f32_nonneg(lbest);
             unsigned long long eq = __ballot(lbest == dmin);
-            int rbi = 0x7fffffff;
+            int rbi = 0, roi = 0x7fffffff;
             while (eq) {
                 const int l = __ffsll((long long)eq) - 1;
                 eq &= eq - 1;
-                rbi = min(rbi, __builtin_amdgcn_readlane(lbi, l));
+                const int oi_ = __builtin_amdgcn_readlane(loi, l);
+                const int bi_ = __builtin_amdgcn_readlane(lbi, l);
+                if (oi_ <= roi) { roi = oi_; rbi = bi_; }
             }
-            if (lane == k) { pbest = dmin; pbi = rbi; }   // carried into the next chunk / stored below
+            if (lane == k) { pbest = dmin; pbi = rbi; poi = roi; }   // carried into the next chunk / stored below
         }
     }
     if (lane < nk) {

@@ -263,3 +263,36 @@ def test_empty_and_degenerate_frames_in_batch(ctx, O, template, frames4):
     _same_cluster(res[1].clusters[0], o1.clusters[0])
     o2 = O.process_frame(planeonly, prm, template)["result"]
     assert (res[2].n_voxels, res[2].n_plane, res[2].n_objects, res[2].n_clusters) == (o2.n_voxels, o2.n_plane, o2.n_objects, o2.n_clusters)
+
+
+def test_icp_exact_ties_pick_lowest_original_index(ctx, O):
+    """Queries exactly equidistant from 2, 4 or 8 template points (lattice with dyadic coordinates,
+    template order shuffled so original-index order is unrelated to the library's internal spatial
+    tiling): the neighbour must be the lowest ORIGINAL index, as in the oracle's ascending scan."""
+    rng = np.random.RandomState(17)
+    g = np.arange(8) / 16.0
+    lat = np.stack(np.meshgrid(g, g, g, indexing="ij"), -1).reshape(-1, 3).astype(np.float32)
+    tpl = lat[rng.permutation(len(lat))]
+    ctx.set_template(2, tpl)
+    half = 1.0 / 32.0
+    q = []
+    for _ in range(400):
+        base = g[rng.randint(0, 7, 3)]
+        kind = rng.randint(0, 4)
+        off = np.array([half, 0, 0]) if kind == 0 else np.array([half, half, 0]) if kind == 1 else \
+            np.array([half, half, half]) if kind == 2 else rng.uniform(0, 1 / 16, 3)
+        q.append(base + rng.permutation(off))
+    q = np.array(q, np.float32)
+    i0, d0 = O.nn(tpl, q, mode=0)
+    i1, d1 = O.nn(tpl, q, mode=1)
+    assert np.array_equal(i0, i1)
+    # at least a third of the queries have an exact multi-way tie
+    d_all = ((q[:, None, :] - tpl[None, :, :]) ** 2).sum(-1)
+    assert ((d_all == d_all.min(1, keepdims=True)).sum(1) > 1).mean() > 0.3
+    prm = capi.default_params()
+    prm.icp_max_iterations = 1
+    st, res, al = ctx.icp(2, q, prm, want_aligned=True)
+    s0, r0, a0 = O.icp(tpl, q, prm, nn_mode=0, want_aligned=True)
+    assert st == s0 == 0
+    _same_cluster(res, r0)
+    assert np.array_equal(al.view(np.uint32), a0.view(np.uint32))
