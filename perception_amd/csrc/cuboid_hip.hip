@@ -48,6 +48,8 @@ struct cd_context {
     float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
     float* d_d2 = nullptr;                                        // its squared distance
+    int* d_queue = nullptr;                                       // ICP work queue head
+    int n_cu = 256;
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
     // ICP
@@ -296,7 +298,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int group = 16;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, ncl, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, ip);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, ncl, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
@@ -511,7 +513,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -554,7 +556,11 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
-    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess;
+    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)4) == hipSuccess;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
+    }
     const size_t ncl = F * KICP;
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;

@@ -189,7 +189,7 @@ __device__ __forceinline__ void xform(const float* T, float x, float y, float z,
 // ---------------------------------------------------------------------------------------
 constexpr int ICPT_THREADS = 1024;                 // 16 waves, 4 per SIMD
 constexpr int ICPT_WAVES = ICPT_THREADS / WAVE;
-constexpr int ICPT_TPL_LDS = 8192;                 // template points resident in LDS per pass (128 KiB)
+constexpr int ICPT_TPL_LDS = 7616;                 // template points resident in LDS per pass (119 runs, 119 KiB)
 constexpr int ICPT_IMG = ICPT_TPL_LDS + ICP_SUB;   // + one pad run
 
 #ifdef CD_STATS
@@ -226,112 +226,124 @@ __device__ __forceinline__ float wave_min_f32_nonneg(float v) {
     return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)x, 63));
 }
 
-// NN of every query of the block's slice (nq <= 1024): results to nn[] / d2buf[].
-// Wave w owns queries w, w+16, w+32, ...; lane k of the wave fetches query k's point, seed and
-// seed distance up front (one batched round of global loads per wave), then the wave walks its
-// queries with the point broadcast out of lane k by v_readlane (wave-uniform, lives in SGPRs).
-// use_prev: seeds are the previous launch's neighbours (nn[]); otherwise a coarse seed (best of
-// the first point of every run).  apply_T: queries are Tm * pts (fitness pass).
-__device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const float4* __restrict__ blo,
-                                         const float4* __restrict__ bhi, int m, float4* s_tpl, const float4* pts,
-                                         int nq, bool use_prev, bool coarse, bool apply_T, const float* Tm, int* nn, float* d2buf) {
+// Boxes of runs `lane` and `lane+64` of the staged chunk, kept in registers.
+struct RunBoxes { float4 L0, H0, L1, H1; };
+
+// Stage template chunk [c0, c0+cn) into LDS: the chunk, its last run padded to 64 points, plus one
+// whole pad run; pad points sit at +inf with original index INT_MAX, so their distance is +inf and
+// they can never win (removes every bounds predicate from the search).  Ends with a barrier.
+__device__ __forceinline__ void stage_chunk(const float4* __restrict__ tpl, const float4* __restrict__ blo,
+                                            const float4* __restrict__ bhi, int c0, int cn, float4* s_tpl, RunBoxes& bx) {
+    const int lane = threadIdx.x & 63;
+    const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
+    const float inf = __uint_as_float(0x7f800000u);
+    __syncthreads();
+    for (int k = threadIdx.x; k < (nruns + 1) * ICP_SUB; k += ICPT_THREADS)
+        s_tpl[k] = k < cn ? tpl[c0 + k] : make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
+    bx.L0 = make_float4(inf, inf, inf, 0.f); bx.H0 = bx.L0; bx.L1 = bx.L0; bx.H1 = bx.L0;
+    if (lane < nruns) { bx.L0 = blo[c0 / ICP_SUB + lane]; bx.H0 = bhi[c0 / ICP_SUB + lane]; }
+    if (lane + 64 < nruns) { bx.L1 = blo[c0 / ICP_SUB + lane + 64]; bx.H1 = bhi[c0 / ICP_SUB + lane + 64]; }
+    __syncthreads();
+}
+
+// Per-wave query state: lane k of a wave holds query (wave + 16*k) of the slice.
+struct QueryRegs { float px, py, pz, pbest; int pbi, poi; };
+
+// Batched fetch of the wave's queries + seeds (one round of global loads per wave).
+// use_prev: seeds are the previous launch's neighbours (nn[]); coarse: also try the first point of
+// every run (worth its m/64 tests while the cloud still moves a lot between launches).
+__device__ __forceinline__ void fetch_queries(const float4* __restrict__ tpl, int m, const float4* pts, int nq, bool use_prev,
+                                              bool coarse, bool apply_T, const float* Tm, const int* nn, QueryRegs& q, int& nk) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int myq = wave + ICPT_WAVES * lane;          // the query this lane fetches / stores
-    const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;   // queries of this wave
-    float px = 0.f, py = 0.f, pz = 0.f, pbest = 0.f;
-    int pbi = 0, poi = 0x7fffffff;   // stored position of the best point and its ORIGINAL template index
+    const int myq = wave + ICPT_WAVES * lane;
+    nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+    q.px = q.py = q.pz = q.pbest = 0.f;
+    q.pbi = 0; q.poi = 0x7fffffff;
     if (lane < nk) {
         const float4 p = pts[myq];
-        px = p.x; py = p.y; pz = p.z;
-        if (apply_T) xform(Tm, p.x, p.y, p.z, px, py, pz);
-        // seed = better of (previous launch's neighbour, best first-point-of-run).  The coarse scan is
-        // only worth its 114 tests while the cloud still moves a lot between launches.
-        pbest = 3.402823466e38f;
+        q.px = p.x; q.py = p.y; q.pz = p.z;
+        if (apply_T) xform(Tm, p.x, p.y, p.z, q.px, q.py, q.pz);
+        q.pbest = 3.402823466e38f;
         if (use_prev) {
-            pbi = nn[myq];
-            const float4 q0 = tpl[pbi];
-            pbest = dist2(px, py, pz, q0.x, q0.y, q0.z);
+            q.pbi = nn[myq];
+            const float4 q0 = tpl[q.pbi];
+            q.pbest = dist2(q.px, q.py, q.pz, q0.x, q0.y, q0.z);
         }
-        if (coarse) {
+        if (coarse || !use_prev) {
             for (int j = 0; j < m; j += ICP_SUB) {
                 const float4 t = tpl[j];
-                const float d = dist2(px, py, pz, t.x, t.y, t.z);
-                if (d < pbest) { pbest = d; pbi = j; }
+                const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                if (d < q.pbest) { q.pbest = d; q.pbi = j; }
             }
         }
-        pbest = seed_bound(pbest);
-        poi = __float_as_int(tpl[pbi].w);
+        q.pbest = seed_bound(q.pbest);
+        q.poi = __float_as_int(tpl[q.pbi].w);
     }
-    for (int c0 = 0; c0 < m; c0 += ICPT_TPL_LDS) {
-        const int cn = min(ICPT_TPL_LDS, m - c0);
-        const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
-        __syncthreads();
-        // image = the chunk, its last run padded to 64 points, plus one whole pad run; pad points sit at
-        // +inf so their distance is +inf and they can never win (removes every bounds predicate below)
-        const float inf = __uint_as_float(0x7f800000u);
-        for (int k = threadIdx.x; k < (nruns + 1) * ICP_SUB; k += ICPT_THREADS)
-            s_tpl[k] = k < cn ? tpl[c0 + k] : make_float4(inf, inf, inf, __int_as_float(0x7fffffff));
-        // boxes of runs `lane` and `lane+64` of this chunk; an absent run gets an unreachable box
-        float4 L0 = make_float4(inf, inf, inf, 0.f), H0 = L0, L1 = L0, H1 = L0;
-        if (lane < nruns) { L0 = blo[c0 / ICP_SUB + lane]; H0 = bhi[c0 / ICP_SUB + lane]; }
-        if (lane + 64 < nruns) { L1 = blo[c0 / ICP_SUB + lane + 64]; H1 = bhi[c0 / ICP_SUB + lane + 64]; }
-        __syncthreads();
-        for (int k = 0; k < nk; ++k) {
-            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(px), k));
-            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(py), k));
-            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pz), k));
-            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pbest), k));
-            const int bi = __builtin_amdgcn_readlane(pbi, k);
-            const int boi = __builtin_amdgcn_readlane(poi, k);
-            unsigned long long m0 = __ballot(box_lb(L0, H0, x, y, z) <= best);
-            unsigned long long m1 = __ballot(box_lb(L1, H1, x, y, z) <= best);
+}
+
+// Search the staged chunk for all nk queries of this wave; updates q in place.
+__device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes& bx, int c0, int cn, QueryRegs& q, int nk) {
+    const int lane = threadIdx.x & 63;
+    const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
+    for (int k = 0; k < nk; ++k) {
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+        const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+        const int bi = __builtin_amdgcn_readlane(q.pbi, k);
+        const int boi = __builtin_amdgcn_readlane(q.poi, k);
+        unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
+        unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
 #ifdef CD_STATS
-            if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+        if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
-            float lbest = best;
-            int lbi = bi, loi = boi;
-            // Visit the surviving runs, two LDS reads in flight at a time.  The template is stored
-            // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
-            // order: the update is the lexicographic (d2, original index) comparison (rule C5).
-            const int pad = nruns;   // index of the all-inf pad run (its original index is INT_MAX)
+        float lbest = best;
+        int lbi = bi, loi = boi;
+        // Visit the surviving runs, two LDS reads in flight at a time.  The template is stored
+        // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
+        // order: the update is the lexicographic (d2, original index) comparison (rule C5).
+        const int pad = nruns;   // index of the all-inf pad run (its original index is INT_MAX)
 #define CD_TAKE(dd, tt, rr)                                                                     \
-            {                                                                                   \
-                const int oi_ = __float_as_int(tt.w);                                           \
-                const bool up_ = (dd < lbest) || (dd == lbest && oi_ < loi);                    \
-                lbest = up_ ? dd : lbest; lbi = up_ ? c0 + rr * ICP_SUB + lane : lbi; loi = up_ ? oi_ : loi; \
-            }
+        {                                                                                       \
+            const int oi_ = __float_as_int(tt.w);                                               \
+            const bool up_ = (dd < lbest) || (dd == lbest && oi_ < loi);                        \
+            lbest = up_ ? dd : lbest; lbi = up_ ? c0 + rr * ICP_SUB + lane : lbi; loi = up_ ? oi_ : loi; \
+        }
 #define CD_VISIT2(mask, base)                                                                   \
-            while (mask) {                                                                      \
-                const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;         \
-                const int r1 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
-                const float4 t0 = s_tpl[r0 * ICP_SUB + lane], t1 = s_tpl[r1 * ICP_SUB + lane];  \
-                const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                              \
-                const float d1 = dist2(x, y, z, t1.x, t1.y, t1.z);                              \
-                CD_TAKE(d0, t0, r0)                                                             \
-                CD_TAKE(d1, t1, r1)                                                             \
-            }
-            CD_VISIT2(m0, 0)
-            CD_VISIT2(m1, 64)
+        while (mask) {                                                                          \
+            const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;             \
+            const int r1 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
+            const float4 t0 = s_tpl[r0 * ICP_SUB + lane], t1 = s_tpl[r1 * ICP_SUB + lane];      \
+            const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                                  \
+            const float d1 = dist2(x, y, z, t1.x, t1.y, t1.z);                                  \
+            CD_TAKE(d0, t0, r0)                                                                 \
+            CD_TAKE(d1, t1, r1)                                                                 \
+        }
+        CD_VISIT2(m0, 0)
+        CD_VISIT2(m1, 64)
 #undef CD_VISIT2
 #undef CD_TAKE
-            // lexicographic (d2, original index) minimum over the wave: min distance by DPP, then the
-            // lowest original index among the lanes that hold it (almost always exactly one lane)
-            const float dmin = wave_min_f32_nonneg(lbest);
-            unsigned long long eq = __ballot(lbest == dmin);
-            int rbi = 0, roi = 0x7fffffff;
-            while (eq) {
-                const int l = __ffsll((long long)eq) - 1;
-                eq &= eq - 1;
-                const int oi_ = __builtin_amdgcn_readlane(loi, l);
-                const int bi_ = __builtin_amdgcn_readlane(lbi, l);
-                if (oi_ <= roi) { roi = oi_; rbi = bi_; }
-            }
-            if (lane == k) { pbest = dmin; pbi = rbi; poi = roi; }   // carried into the next chunk / stored below
+        // lexicographic (d2, original index) minimum over the wave: min distance by DPP, then the
+        // lowest original index among the lanes that hold it (almost always exactly one lane)
+        const float dmin = wave_min_f32_nonneg(lbest);
+        unsigned long long eq = __ballot(lbest == dmin);
+        int rbi = 0, roi = 0x7fffffff;
+        while (eq) {
+            const int l = __ffsll((long long)eq) - 1;
+            eq &= eq - 1;
+            const int oi_ = __builtin_amdgcn_readlane(loi, l);
+            const int bi_ = __builtin_amdgcn_readlane(lbi, l);
+            if (oi_ <= roi) { roi = oi_; rbi = bi_; }
         }
+        if (lane == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
     }
+}
+
+__device__ __forceinline__ void store_queries(const QueryRegs& q, int nk, int* nn, float* d2buf) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < nk) {
-        nn[myq] = pbi;
-        d2buf[myq] = pbest;
+        nn[wave + ICPT_WAVES * lane] = q.pbi;
+        d2buf[wave + ICPT_WAVES * lane] = q.pbest;
     }
 }
 
@@ -341,8 +353,9 @@ __device__ __forceinline__ void nn_slice(const float4* __restrict__ tpl, const f
 // clears the moment buffer launch it+1 will accumulate into.
 __global__ void __launch_bounds__(WAVE) k_icp_solve(int it, int ncl, const IcpCluster* __restrict__ cl,
                                                     IcpState* __restrict__ st, unsigned long long* __restrict__ acc,
-                                                    IcpParams prm) {
+                                                    int* __restrict__ queue, IcpParams prm) {
     const int k = blockIdx.x * WAVE + threadIdx.x;
+    if (k == 0) *queue = 0;   // work queue of the k_icp_iter launch that follows
     if (k >= ncl) return;
     const IcpState* sin = st + (size_t)k * 2 + (it & 1);
     IcpState* sout = st + (size_t)k * 2 + ((it + 1) & 1);
@@ -384,54 +397,79 @@ __global__ void __launch_bounds__(WAVE) k_icp_solve(int it, int ncl, const IcpCl
     for (int i = 0; i < 16; ++i) Z[i] = 0ull;
 }
 
-__global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, const IcpWork* __restrict__ work,
+// Persistent: one workgroup per CU.  The template image and this lane's run boxes stay resident
+// while the workgroup pulls (cluster, slice) work items from an atomic queue (zeroed by k_icp_solve).
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, const IcpWork* __restrict__ work,
                                                            const IcpCluster* __restrict__ cl, const IcpState* __restrict__ st,
                                                            unsigned long long* __restrict__ acc,
                                                            const float4* __restrict__ tpl, const float4* __restrict__ tlo,
                                                            const float4* __restrict__ thi, float4* src, int* nn,
-                                                           float* d2buf, int qslice) {
+                                                           float* d2buf, int qslice, int* queue) {
     __shared__ float4 s_tpl[ICPT_IMG];
-    const IcpWork wk = work[blockIdx.x];
-    const IcpCluster c = cl[wk.cluster];
-    const IcpState* sin = st + (size_t)wk.cluster * 2 + (it & 1);          // state before this launch
-    const IcpState* snow = st + (size_t)wk.cluster * 2 + ((it + 1) & 1);   // written by k_icp_solve(it)
+    __shared__ unsigned long long s_scr[8 * ICP_QSLICE];   // moment scratch, 8 terms at a time (32 KiB)
+    __shared__ int s_item;
     const int lane = threadIdx.x & 63;
-    if (sin->done) return;
-    const int done_now = snow->done;
-    const int q0 = wk.tile * qslice;
-    const int nq = min(qslice, c.n - q0);
-    float4* pts = src + c.src_off + q0;
-    int* nnq = nn + c.src_off + q0;
-    float* d2q = d2buf + c.src_off + q0;
-    if (it > 0) {   // X <- T * X, in place
-        float T[12];
+    RunBoxes bx;
+    int staged = -1;   // template offset whose (single-chunk) image is resident in LDS
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(queue, 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_work) break;
+        const IcpWork wk = work[item];
+        const IcpCluster c = cl[wk.cluster];
+        const IcpState* sin = st + (size_t)wk.cluster * 2 + (it & 1);          // state before this launch
+        const IcpState* snow = st + (size_t)wk.cluster * 2 + ((it + 1) & 1);   // written by k_icp_solve(it)
+        if (sin->done) continue;
+        const int done_now = snow->done;
+        const int q0 = wk.tile * qslice;
+        const int nq = min(qslice, c.n - q0);
+        float4* pts = src + c.src_off + q0;
+        int* nnq = nn + c.src_off + q0;
+        float* d2q = d2buf + c.src_off + q0;
+        if (it > 0) {   // X <- T * X, in place
+            float T[12];
 #pragma unroll
-        for (int k = 0; k < 12; ++k) T[k] = snow->T[k];
-        for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) {
-            const float4 p = pts[i];
-            float ox, oy, oz;
-            xform(T, p.x, p.y, p.z, ox, oy, oz);
-            pts[i] = make_float4(ox, oy, oz, p.w);
+            for (int k = 0; k < 12; ++k) T[k] = snow->T[k];
+            for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) {
+                const float4 p = pts[i];
+                float ox, oy, oz;
+                xform(T, p.x, p.y, p.z, ox, oy, oz);
+                pts[i] = make_float4(ox, oy, oz, p.w);
+            }
         }
-    }
-    if (done_now) return;
-    __syncthreads();   // the transformed points are read by other waves below
-    static_assert(ICP_QSLICE <= ICPT_THREADS && 16 * ICP_QSLICE * 8 <= ICPT_TPL_LDS * 16, "slice must fit the block / LDS scratch");
-    nn_slice(tpl + c.tpl_off, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, pts, nq, it > 0, it < 6, false,
-             nullptr, nnq, d2q);
-    __syncthreads();
-    // 16 fixed-point moments of the correspondences of this slice: per-point terms go to LDS
-    // (term-major, conflict-free; the template image is dead by now), wave k then sums term k.
-    unsigned long long* scratch = reinterpret_cast<unsigned long long*>(s_tpl);   // 16 x ICP_QSLICE x 8 B = 64 KiB
-    if (threadIdx.x < ICP_QSLICE) {
-        const int i = threadIdx.x;
+        if (done_now) continue;
+        __syncthreads();   // the transformed points are read by other waves below
+        const float4* tp = tpl + c.tpl_off;
+        const float4* blo = tlo + c.tpl_off / ICP_SUB;
+        const float4* bhi = thi + c.tpl_off / ICP_SUB;
+        QueryRegs q;
+        int nk;
+        fetch_queries(tp, c.tpl_m, pts, nq, it > 0, it < 6, false, nullptr, nnq, q, nk);
+        if (c.tpl_m <= ICPT_TPL_LDS) {
+            if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
+            search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+        } else {
+            for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                search_chunk(s_tpl, bx, c0, cn, q, nk);
+            }
+            staged = -1;
+        }
+        store_queries(q, nk, nnq, d2q);
+        __syncthreads();
+        // 16 fixed-point moments of the correspondences of this slice: per-point terms go to LDS
+        // (term-major, conflict-free), 8 terms at a time; wave k then sums term k.
         unsigned long long S[16];
 #pragma unroll
         for (int k = 0; k < 16; ++k) S[k] = 0ull;
-        if (i < nq) {
+        if (threadIdx.x < nq) {
+            const int i = threadIdx.x;
             const float4 p = pts[i];
-            const float4 q = tpl[c.tpl_off + nnq[i]];
-            const float pv[3] = {p.x, p.y, p.z}, qv[3] = {q.x, q.y, q.z};
+            const float4 qq = tp[nnq[i]];
+            const float pv[3] = {p.x, p.y, p.z}, qv[3] = {qq.x, qq.y, qq.z};
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
@@ -441,17 +479,24 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, const IcpWork
             }
             S[15] = (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
         }
+        static_assert(ICP_QSLICE <= ICPT_THREADS, "one point per thread in the moment pass");
 #pragma unroll
-        for (int k = 0; k < 16; ++k) scratch[k * ICP_QSLICE + i] = S[k];
-    }
-    __syncthreads();
-    {
-        const int k = threadIdx.x >> 6;   // 16 waves <-> 16 moments
-        unsigned long long t = 0ull;
+        for (int h = 0; h < 2; ++h) {
+            if (h) __syncthreads();
+            if (threadIdx.x < ICP_QSLICE) {
 #pragma unroll
-        for (int j = 0; j < ICP_QSLICE / 64; ++j) t += scratch[k * ICP_QSLICE + j * 64 + lane];
-        t = wave_sum_u64(t);
-        if (lane == 0) atomicAdd(&acc[((size_t)wk.cluster * 3 + it % 3) * 16 + k], t);
+                for (int k = 0; k < 8; ++k) s_scr[k * ICP_QSLICE + threadIdx.x] = S[8 * h + k];
+            }
+            __syncthreads();
+            const int k = threadIdx.x >> 6;   // waves 0..7 <-> the 8 moments of this half
+            if (k < 8) {
+                unsigned long long t = 0ull;
+#pragma unroll
+                for (int j = 0; j < ICP_QSLICE / 64; ++j) t += s_scr[k * ICP_QSLICE + j * 64 + lane];
+                t = wave_sum_u64(t);
+                if (lane == 0) atomicAdd(&acc[((size_t)wk.cluster * 3 + it % 3) * 16 + 8 * h + k], t);
+            }
+        }
     }
 }
 
@@ -480,8 +525,19 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
     const int nq = min(qslice, c.n - q0);
     int* nnq = nn + c.src_off + q0;
     float* d2q = d2buf + c.src_off + q0;
-    nn_slice(tpl + c.tpl_off, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c.tpl_m, s_tpl, src0 + c.src_off + q0, nq,
-             true, false, true, T, nnq, d2q);
+    {
+        const float4* tp = tpl + c.tpl_off;
+        QueryRegs q;
+        RunBoxes bx;
+        int nk;
+        fetch_queries(tp, c.tpl_m, src0 + c.src_off + q0, nq, true, false, true, T, nnq, q, nk);
+        for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+            const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+            stage_chunk(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c0, cn, s_tpl, bx);
+            search_chunk(s_tpl, bx, c0, cn, q, nk);
+        }
+        store_queries(q, nk, nnq, d2q);
+    }
     __syncthreads();
     unsigned long long v = 0ull;
     for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) v += (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
@@ -495,10 +551,11 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
 
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                      unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
-                     int* nn, float* d2buf, int qslice, IcpParams prm) {
+                     int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_solve, dim3((ncl + WAVE - 1) / WAVE), dim3(WAVE), 0, s, it, ncl, cl, st, acc, prm);
-    hipLaunchKernelGGL(k_icp_iter, dim3(n_work), dim3(ICPT_THREADS), 0, s, it, work, cl, st, acc, tpl, tlo, thi, src, nn, d2buf, qslice);
+    hipLaunchKernelGGL(k_icp_solve, dim3((ncl + WAVE - 1) / WAVE), dim3(WAVE), 0, s, it, ncl, cl, st, acc, queue, prm);
+    hipLaunchKernelGGL(k_icp_iter, dim3(n_work < n_cu ? n_work : n_cu), dim3(ICPT_THREADS), 0, s, it, n_work, work, cl, st, acc, tpl, tlo,
+                       thi, src, nn, d2buf, qslice, queue);
 }
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
