@@ -38,7 +38,7 @@ struct cd_context {
     float4* d_models = nullptr;
     int *d_valid = nullptr, *d_counts = nullptr, *d_active = nullptr;
     int *h_valid = nullptr, *h_counts = nullptr, *h_active = nullptr;
-    float4 *d_model = nullptr, *h_model = nullptr;
+    float4 *d_model = nullptr, *h_model = nullptr, *h_models = nullptr;
     int *d_have = nullptr, *h_have = nullptr;
     unsigned long long *d_sums = nullptr, *h_sums = nullptr;
     // extract / cluster
@@ -170,8 +170,10 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
         HIPCHK(c, hipMemcpyAsync(c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
         launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, c->d_active, c->d_models, c->d_valid);
         launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, c->d_active, h_prev, h_target, thr, c->d_counts);
-        HIPCHK(c, hipMemcpyAsync(c->h_counts, c->d_counts, sizeof(int) * (size_t)F * MAX_HYP, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_valid, c->d_valid, sizeof(int) * (size_t)F * MAX_HYP, hipMemcpyDeviceToHost, c->stream));
+        // only the first h_target columns of the [F][MAX_HYP] tables are live: one strided copy each
+        HIPCHK(c, hipMemcpy2DAsync(c->h_counts, sizeof(int) * MAX_HYP, c->d_counts, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->h_valid, sizeof(int) * MAX_HYP, c->d_valid, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpy2DAsync(c->h_models, sizeof(float4) * MAX_HYP, c->d_models, sizeof(float4) * MAX_HYP, sizeof(float4) * h_target, F, hipMemcpyDeviceToHost, c->stream));
         int st = sync_fs(c, F);   // sync #2 (per round): counts + n_hyp
         if (st) return st;
         ++rounds;
@@ -192,10 +194,8 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
         iterations[f] = rep[f].iterations;
         c->h_have[f] = rep[f].best_h >= 0 ? 1 : 0;
         c->h_model[f] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c->h_have[f])
-            HIPCHK(c, hipMemcpyAsync(&c->h_model[f], c->d_models + (size_t)f * MAX_HYP + rep[f].best_h, sizeof(float4), hipMemcpyDeviceToHost, c->stream));
+        if (c->h_have[f]) c->h_model[f] = c->h_models[(size_t)f * MAX_HYP + rep[f].best_h];
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_have, c->h_have, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
     if (p->plane_optimize) {
@@ -240,6 +240,11 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint) {
     const float inv_cell = 1.0f / cell;
     const float r2 = (float)(p->cluster_tolerance * p->cluster_tolerance);
     if (p->cluster_enable) {
+        // frames with <= 8192 object points (the usual case) are clustered by one workgroup in LDS ...
+        launch_cluster_lds(c->stream, c->d_obj, c->N, F, c->d_fs, inv_cell, r2, c->d_parent, c->d_csize, c->d_rank);
+    }
+    if (p->cluster_enable && max_no_hint > 8192) {
+        // ... larger ones by the global-memory path (its kernels skip the small frames)
         HIPCHK(c, hipMemsetAsync(c->d_head, 0xff, sizeof(int) * (size_t)F * CELL_BUCKETS, c->stream));
         launch_cluster_build(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, c->d_head, c->d_next, c->d_parent, c->d_csize, c->d_rank);
         launch_cluster_hook(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, r2, c->d_head, c->d_next, c->d_parent);
@@ -384,9 +389,11 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     st = stage_extract(c, F, p);
     if (st) return st;
-    int max_nv = 0;
-    for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
-    st = stage_cluster(c, F, p, max_nv);
+    st = sync_fs(c, F);   // n_o per frame: picks the LDS / global clustering path and sizes the launches
+    if (st) return st;
+    int max_no = 0;
+    for (int f = 0; f < F; ++f) max_no = std::max(max_no, c->h_fs[f].n_o);
+    st = stage_cluster(c, F, p, max_no);
     if (st) return st;
     st = sync_fs(c, F);   // sync #4: n_plane, n_o, n_k, ksize, koff
     if (st) return st;
@@ -515,7 +522,7 @@ void cd_destroy(cd_context* c) {
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
-    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
+    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -545,7 +552,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_hist, F * RADIX * T) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
-    ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess;
+    ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess && halloc(&c->h_models, F * MAX_HYP) == hipSuccess;
     ok = ok && dalloc(&c->d_active, F) == hipSuccess && halloc(&c->h_active, F) == hipSuccess;
     ok = ok && dalloc(&c->d_model, F) == hipSuccess && halloc(&c->h_model, F) == hipSuccess;
     ok = ok && dalloc(&c->d_have, F) == hipSuccess && halloc(&c->h_have, F) == hipSuccess;

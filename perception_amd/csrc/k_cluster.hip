@@ -15,6 +15,8 @@
 
 namespace cd {
 
+constexpr int CL_LDS_CAP_GLOBAL_SKIP = 8192;   // == CL_LDS_CAP: frames this small are clustered in LDS
+
 __device__ __forceinline__ int ld_agent(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -37,6 +39,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_build(const float4* __restric
                                                          int* __restrict__ rank_of_root) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
+    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
     const size_t fbase = (size_t)f * N;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         int cx, cy, cz;
@@ -70,12 +73,17 @@ __device__ __forceinline__ void uf_union(int* par, int a, int b) {
     }
 }
 
-// Cheap find for the hot loop: plain (L1-cacheable) loads, no writes.  A stale value is always
+// Cheap find for the hot loop: plain (L1-cacheable) loads, path halving by write-through stores.  A stale value is always
 // a past parent, i.e. still an ancestor-or-self, so a stale "root" only makes the CAS below fail,
 // after which the slow path re-reads with agent-scope atomics.
-__device__ __forceinline__ int uf_find_cached(const int* par, int x) {
+__device__ __forceinline__ int uf_find_cached(int* par, int x) {
     int p = par[x];
-    while (p != x) { x = p; p = par[x]; }
+    while (p != x) {
+        const int gp = par[p];
+        if (gp != p) st_agent(par + x, gp);   // path halving: x is not a root, gp is one of its ancestors
+        x = p;
+        p = gp;
+    }
     return x;
 }
 
@@ -85,6 +93,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
                                                         int* parent) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
+    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
     const size_t fbase = (size_t)f * N;
     const float4* P = obj + fbase;
     const int* nx = next + fbase;
@@ -125,6 +134,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameSta
                                                            int* __restrict__ parent, int* __restrict__ csize) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
+    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
     int* par = parent + (size_t)f * N;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         int r = i;
@@ -135,6 +145,108 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameSta
         }
         if (r != i) st_agent(par + i, r);
         atomicAdd(&csize[(size_t)f * N + r], 1);
+    }
+}
+
+// ---- LDS variant: one 1024-thread workgroup per frame, for frames with n_o <= CL_LDS_CAP ----------
+// Points, the cell hash (heads + next links) and the union-find parents all live in LDS, so the
+// hooking phase runs at LDS latency and is coherent by construction (one CU).  Produces exactly what
+// build + hook + flatten produce (parent = root = smallest member index, component sizes).
+constexpr int CL_LDS_CAP = 8192;
+constexpr int CL_LDS_BUCKETS = 8192;
+constexpr int CL_THREADS = 1024;
+constexpr int CL_PER_THREAD = CL_LDS_CAP / CL_THREADS;
+
+__device__ __forceinline__ uint32_t cell_hash_lds(int cx, int cy, int cz) {
+    return ((uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u) & (CL_LDS_BUCKETS - 1);
+}
+// find with path halving; parents live in LDS (coherent within the workgroup).  A halving store
+// only ever re-points a NON-root at one of its ancestors, so it cannot disturb the root CAS.
+__device__ __forceinline__ int lds_find(int* par, int x) {
+    int p = par[x];
+    while (p != x) {
+        const int gp = par[p];
+        if (gp != p) par[x] = gp;
+        x = p;
+        p = gp;
+    }
+    return x;
+}
+
+__global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __restrict__ obj, int N,
+                                                            const FrameState* __restrict__ fs, float inv_cell, float r2,
+                                                            int* __restrict__ parent, int* __restrict__ csize,
+                                                            int* __restrict__ rank_of_root) {
+    __shared__ int s_par[CL_LDS_CAP];         // 32 KiB
+    __shared__ int s_next[CL_LDS_CAP];        // 32 KiB (reused as the size counters at the end)
+    __shared__ int s_head[CL_LDS_BUCKETS];    // 32 KiB
+    const int f = blockIdx.x;
+    const int n = fs[f].n_o;
+    if (n <= 0 || n > CL_LDS_CAP) return;     // larger frames take the global-memory path
+    const size_t fbase = (size_t)f * N;
+    const float4* __restrict__ P = obj + fbase;   // read-only in this kernel: plain cached loads
+    const float org[3] = {fs[f].origin[0], fs[f].origin[1], fs[f].origin[2]};
+    for (int i = threadIdx.x; i < CL_LDS_BUCKETS; i += CL_THREADS) s_head[i] = -1;
+    for (int i = threadIdx.x; i < n; i += CL_THREADS) s_par[i] = i;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += CL_THREADS) {
+        int cx, cy, cz;
+        cell_of(P[i], org, inv_cell, cx, cy, cz);
+        s_next[i] = atomicExch(&s_head[cell_hash_lds(cx, cy, cz)], i);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += CL_THREADS) {
+        const float4 p = P[i];
+        int cx, cy, cz;
+        cell_of(p, org, inv_cell, cx, cy, cz);
+        int ri = lds_find(s_par, i);
+        for (int a = -1; a <= 1; ++a)
+            for (int b = -1; b <= 1; ++b)
+                for (int c = -1; c <= 1; ++c) {
+                    int j = s_head[cell_hash_lds(cx + a, cy + b, cz + c)];
+                    while (j >= 0) {
+                        if (j < i) {
+                            const float4 q = P[j];
+                            if (dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+                                int rj = lds_find(s_par, j);
+                                while (ri != rj) {
+                                    const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
+                                    const int old = atomicCAS(&s_par[hi], hi, lo);   // link the larger root under the smaller
+                                    if (old == hi) { ri = lo; rj = lo; break; }
+                                    ri = lds_find(s_par, ri);                        // hi had been linked meanwhile: climb and retry
+                                    rj = lds_find(s_par, rj);
+                                }
+                                ri = ri < rj ? ri : rj;
+                            }
+                        }
+                        j = s_next[j];
+                    }
+                }
+    }
+    __syncthreads();
+    int root[CL_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CL_THREADS;
+        root[k] = i < n ? lds_find(s_par, i) : 0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += CL_THREADS) s_next[i] = 0;   // links are dead: reuse as size counters
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CL_THREADS;
+        if (i < n) atomicAdd(&s_next[root[k]], 1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = threadIdx.x + k * CL_THREADS;
+        if (i < n) {
+            parent[fbase + i] = root[k];
+            csize[fbase + i] = s_next[i];
+            rank_of_root[fbase + i] = -1;
+        }
     }
 }
 
@@ -288,6 +400,11 @@ static inline int grid_for(int n_max) {
     return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
+void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, const FrameState* fs, float inv_cell, float r2,
+                        int* parent, int* csize, int* rank_of_root) {
+    static_assert(CL_LDS_CAP == CL_LDS_CAP_GLOBAL_SKIP, "LDS / global split must agree");
+    hipLaunchKernelGGL(k_cluster_lds, dim3(F), dim3(CL_THREADS), 0, s, obj, N, fs, inv_cell, r2, parent, csize, rank_of_root);
+}
 void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
                           int* head, int* next, int* parent, int* csize, int* rank_of_root) {
     hipLaunchKernelGGL(k_cluster_build, dim3(grid_for(Tact * TILE), F), dim3(BLOCK), 0, s, obj, N, fs, inv_cell, head, next,
