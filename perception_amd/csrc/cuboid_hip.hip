@@ -54,7 +54,7 @@ struct cd_context {
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
     // ICP
     IcpCluster *d_cl = nullptr, *h_cl = nullptr;
-    IcpWork *d_work = nullptr, *h_work = nullptr;
+    IcpWork *d_work = nullptr, *h_work = nullptr, *d_work2 = nullptr, *h_work2 = nullptr;
     int work_cap = 0;
     IcpState *d_st = nullptr, *h_st = nullptr;
     unsigned long long *d_acc = nullptr, *d_accf = nullptr, *h_accf = nullptr;
@@ -300,15 +300,32 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     int it = 0;
     const int max_launch = p->icp_max_iterations + 3;
-    int group = 16;
+    // The iteration kernel walks an ACTIVE work list (d_work2) that the host re-packs at every
+    // completion poll, dropping the clusters that have converged; the full list (d_work) is kept for
+    // the fitness pass.  A cluster whose state shows done in either parity slot has already had its
+    // final transform applied, so it needs no further work items (k_icp_solve alone keeps its state).
+    int nactive = nwork;
+    std::memcpy(c->h_work2, c->h_work, sizeof(IcpWork) * (size_t)std::max(nwork, 1));
+    HIPCHK(c, hipMemcpyAsync(c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)std::max(nwork, 1), hipMemcpyHostToDevice, c->stream));
+    int group = 8;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nwork, ncl, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
+        int na = 0;
+        for (int w = 0; w < nwork; ++w) {
+            const int k = c->h_work[w].cluster;
+            if (!(c->h_st[2 * k].done || c->h_st[2 * k + 1].done)) c->h_work2[na++] = c->h_work[w];
+        }
         for (int k = 0; k < ncl && all; ++k) all = c->h_st[2 * k].done && c->h_st[2 * k + 1].done;
         if (all) break;
+        if (na != nactive) {
+            nactive = na;
+            if (na > 0) HIPCHK(c, hipMemcpyAsync(c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+        }
+        group = 16;
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
@@ -520,9 +537,9 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_cl, c->d_work, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
-    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_st, c->h_accf};
+    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -572,6 +589,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
+    ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;
     ok = ok && dalloc(&c->d_acc, ncl * 48) == hipSuccess && dalloc(&c->d_accf, ncl) == hipSuccess && halloc(&c->h_accf, ncl) == hipSuccess;
     if (ok) {

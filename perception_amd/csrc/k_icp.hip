@@ -407,16 +407,16 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
                                                            float* d2buf, int qslice, int* queue) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned long long s_scr[8 * ICP_QSLICE];   // moment scratch, 8 terms at a time (32 KiB)
-    __shared__ int s_item;
+    __shared__ int s_item[2];
     const int lane = threadIdx.x & 63;
     RunBoxes bx;
     int staged = -1;   // template offset whose (single-chunk) image is resident in LDS
-    for (;;) {
-        __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(queue, 1);
-        __syncthreads();
-        const int item = s_item;
+    if (threadIdx.x == 0) s_item[0] = atomicAdd(queue, 1);
+    for (int ph = 0;; ph ^= 1) {
+        __syncthreads();                       // one barrier per item: publishes s_item[ph], retires the previous item
+        const int item = s_item[ph];
         if (item >= n_work) break;
+        if (threadIdx.x == 0) s_item[ph ^ 1] = atomicAdd(queue, 1);   // pop the next item while this one is processed
         const IcpWork wk = work[item];
         const IcpCluster c = cl[wk.cluster];
         const IcpState* sin = st + (size_t)wk.cluster * 2 + (it & 1);          // state before this launch
@@ -446,7 +446,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
         const float4* bhi = thi + c.tpl_off / ICP_SUB;
         QueryRegs q;
         int nk;
-        fetch_queries(tp, c.tpl_m, pts, nq, it > 0, it < 6, false, nullptr, nnq, q, nk);
+        fetch_queries(tp, c.tpl_m, pts, nq, it > 0, it < 3, false, nullptr, nnq, q, nk);
         if (c.tpl_m <= ICPT_TPL_LDS) {
             if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
             search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
@@ -552,8 +552,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                      unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
                      int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm) {
-    if (n_work <= 0) return;
+    if (ncl <= 0) return;
     hipLaunchKernelGGL(k_icp_solve, dim3((ncl + WAVE - 1) / WAVE), dim3(WAVE), 0, s, it, ncl, cl, st, acc, queue, prm);
+    if (n_work <= 0) return;   // every cluster converged: only the state bookkeeping above is needed
     hipLaunchKernelGGL(k_icp_iter, dim3(n_work < n_cu ? n_work : n_cu), dim3(ICPT_THREADS), 0, s, it, n_work, work, cl, st, acc, tpl, tlo,
                        thi, src, nn, d2buf, qslice, queue);
 }
