@@ -89,8 +89,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CUBOID_BENCH_FORCE_DIST") == "1"   # force: rehearse the RCCL path with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
@@ -106,11 +108,11 @@ def main():
     def step():
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=results)
         rec = capi.results_to_array(results)
-        return batch.gather_records(rec, F * world, dist if world > 1 else None, dev)
+        return batch.gather_records(rec, F * world, dist if use_dist else None, dev)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -128,7 +130,7 @@ def main():
         stage += np.array(list(t.stage_ms))
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         te = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te.item())
@@ -198,7 +200,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(frames, prm, tpl)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

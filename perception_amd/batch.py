@@ -23,7 +23,7 @@ def gather_records(local_records, n_frames_total, dist=None, device=None):
     Returns uint8 array (n_frames_total, FRAME_RESULT_BYTES) on every rank, frame order."""
     import torch
     rec = np.ascontiguousarray(local_records, dtype=np.uint8)
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         assert rec.shape[0] == n_frames_total
         return rec
     world, rank = dist.get_world_size(), dist.get_rank()

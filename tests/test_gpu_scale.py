@@ -1,0 +1,80 @@
+"""GPU tests at BASELINE.json's larger sizes, through size-independent properties plus one
+oracle comparison at 1 M points (config 5's frame size)."""
+import numpy as np
+import pytest
+
+from perception_amd import capi, synth, templates
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_of_32_equals_32_single_frames(template):
+    """A frame's record must not depend on the batch it travels in (frames are independent:
+    that is what makes frame-per-GPU sharding exact)."""
+    F = 32
+    frames = np.stack([synth.frame(100 + i) for i in range(F)], 0)
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=F)
+    ctx.set_template(0, template)
+    res, pi, lb = ctx.process_batch(frames, prm, want_indices=True)
+    A = capi.results_to_array(res).copy()
+    one = capi.Context(max_points=frames.shape[1], max_frames=1)
+    one.set_template(0, template)
+    for f in range(F):
+        r1, p1, l1 = one.process_batch(frames[f:f + 1], prm, want_indices=True)
+        assert np.array_equal(capi.results_to_array(r1)[0], A[f]), f
+        assert np.array_equal(p1[0], pi[f]) and np.array_equal(l1[0], lb[f])
+    # every frame found its plane and at least one cuboid, and ICP accepted most of them
+    assert all(r.status == 0 and r.n_clusters >= 1 for r in res)
+    acc = sum(r.clusters[k].accepted for r in res for k in range(r.n_clusters))
+    assert acc >= 0.7 * sum(r.n_clusters for r in res)
+    ctx.close()
+    one.close()
+
+
+def test_one_million_point_frame_matches_oracle(O, template):
+    """1000x1000 virtual sensor (1 M points, the frame size of BASELINE config 5), 3 cuboids, two
+    template slots; the second ICP target is the 75 mm-high cuboid template."""
+    sc = synth.scene_for(7, k_obj=3)
+    big = synth.render(sc, width=1000, height=1000)
+    assert big.shape == (1000000, 4)
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    ctx = capi.Context(max_points=big.shape[0], max_frames=1)
+    ctx.set_template(0, template)
+    tall = templates.template_xyz32(0.2, 0.1, 0.075, 0.002)
+    ctx.set_template(1, tall)
+    for slot, tpl in ((0, template), (1, tall)):
+        prm.template_slot = slot
+        res, pi, lb = ctx.process_batch(big[None], prm, want_indices=True)
+        o = O.process_frame(big, prm, tpl, want_clouds=True)
+        rg, ro = res[0], o["result"]
+        assert (rg.n_cropped, rg.n_voxels, rg.n_plane, rg.n_objects, rg.n_clusters) == \
+               (ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters)
+        assert np.array_equal(pi[0][:rg.n_plane], o["plane_inliers"])
+        assert np.array_equal(lb[0][:rg.n_objects], o["labels"])
+        for k in range(min(rg.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+            a, b = rg.clusters[k], ro.clusters[k]
+            assert (a.size, a.iterations, a.converged) == (b.size, b.iterations, b.converged)
+            assert list(a.T) == list(b.T) and a.fitness == b.fitness
+    ctx.close()
+
+
+def test_capacity_and_argument_errors(template):
+    ctx = capi.Context(max_points=1000, max_frames=2)
+    prm = capi.default_params()
+    with pytest.raises(capi.CuboidError) as e:
+        ctx.process_batch(np.zeros((1, 2000, 4), np.float32), prm)
+    assert e.value.status == capi.CD_ERR_CAPACITY
+    with pytest.raises(capi.CuboidError) as e:
+        ctx.process_batch(np.zeros((3, 100, 4), np.float32), prm)
+    assert e.value.status == capi.CD_ERR_CAPACITY
+    with pytest.raises(capi.CuboidError) as e:          # no template in the slot
+        ctx.icp(3, template[:100], prm)
+    assert e.value.status == capi.CD_ERR_NO_TEMPLATE
+    prm.leaf_size = 0.0
+    with pytest.raises(capi.CuboidError) as e:
+        ctx.process_batch(np.zeros((1, 100, 4), np.float32), prm)
+    assert e.value.status == capi.CD_ERR_INVALID_ARG
+    ctx.close()
