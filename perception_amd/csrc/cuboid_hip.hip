@@ -50,6 +50,8 @@ struct cd_context {
     float* d_d2 = nullptr;                                        // its squared distance
     int* d_queue = nullptr;                                       // ICP work queue head
     int n_cu = 256;
+    int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
+    int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
     // ICP
@@ -298,6 +300,31 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     ip.rot_thr = 1.0 - p->icp_transformation_epsilon;
     ip.abs_mse = 1e-12;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    // Batch mode: with at least ~n_cu/2 clusters every CU can own whole clusters, so each cluster runs its
+    // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
+    const bool whole_cluster = c->icp_mode == 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2);
+    if (whole_cluster) {
+        for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
+        std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
+        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
+        launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_src0, c->d_nn,
+                           c->d_queue, c->n_cu, ip);
+        HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+        c->timing.icp_kernel_launches = 1;
+        HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        float ms1 = 0.f;
+        hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
+        c->timing.icp_kernel_ms = ms1;
+        if (pair_tests) {
+            long long tot = 0;
+            for (int k = 0; k < ncl; ++k)
+                if (c->h_st[2 * k].status == CD_OK) tot += (long long)c->h_cl[k].n * c->h_cl[k].tpl_m * (c->h_st[2 * k].iters + 1);
+            *pair_tests = tot;
+        }
+        return CD_OK;
+    }
     int it = 0;
     const int max_launch = p->icp_max_iterations + 3;
     // The iteration kernel walks an ACTIVE work list (d_work2) that the host re-packs at every
@@ -537,9 +564,9 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
-    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_work, c->h_work2, c->h_st, c->h_accf};
+    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -588,6 +615,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     const size_t ncl = F * KICP;
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
+    ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
+    if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : 0);
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;

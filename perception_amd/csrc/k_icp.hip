@@ -500,6 +500,203 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Whole-cluster variant (batch mode): ONE persistent workgroup takes a cluster from the queue
+// (largest first) and runs its complete ICP - every iteration's transform, search, moments,
+// Umeyama/SVD solve and convergence test, then the fitness pass - without leaving the CU.
+// Same arithmetic as k_icp_solve + k_icp_iter + k_icp_fitness (the moments are order-free
+// integer sums), so the results are bit-identical; what disappears are the ~2 launches per
+// iteration, the global moment atomics, the host completion polls and the under-filled tail.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void block_sum16(unsigned long long (&S)[16], unsigned long long (*s_part)[16],
+                                            unsigned long long* s_tot) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const unsigned long long t = wave_sum_u64(S[k]);
+        if (lane == 0) s_part[wave][k] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {
+        unsigned long long t = 0ull;
+#pragma unroll
+        for (int w = 0; w < ICPT_WAVES; ++w) t += s_part[w][threadIdx.x];
+        s_tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int* __restrict__ order,
+                                                              const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
+                                                              unsigned long long* __restrict__ accf,
+                                                              const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                              const float4* __restrict__ thi, float4* src,
+                                                              const float4* __restrict__ src0, int* nn, int* queue,
+                                                              IcpParams prm) {
+    __shared__ float4 s_tpl[ICPT_IMG];
+    __shared__ unsigned long long s_part[ICPT_WAVES][16];
+    __shared__ unsigned long long s_tot[16];
+    __shared__ IcpState s_so;   // the cluster's ICP state (T = current transformation_, Tfinal = accumulated)
+    __shared__ int s_flag[2];   // [0] queue item, [1] done
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    RunBoxes bx;
+    int staged = -1;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_flag[0] = atomicAdd(queue, 1);
+        __syncthreads();
+        const int item = s_flag[0];
+        if (item >= ncl) break;
+        const int k = order[item];
+        const IcpCluster c = cl[k];
+        if (st[2 * (size_t)k].done) continue;            // host pre-marked (too few points / no template)
+        const float4* tp = tpl + c.tpl_off;
+        const float4* blo = tlo + c.tpl_off / ICP_SUB;
+        const float4* bhi = thi + c.tpl_off / ICP_SUB;
+        const bool resident = c.tpl_m <= ICPT_TPL_LDS;
+        if (resident && staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
+        float4* pts = src + c.src_off;
+        int* nnq = nn + c.src_off;
+        if (threadIdx.x == 0) s_so = st[2 * (size_t)k];   // thread 0 owns and updates it
+        int it = 0;
+        for (;; ++it) {
+            unsigned long long S[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = 0ull;
+            for (int q0 = 0; q0 < c.n; q0 += ICPT_THREADS) {
+                const int nq = min(ICPT_THREADS, c.n - q0);
+                const int myq = q0 + wave + ICPT_WAVES * lane;
+                QueryRegs q;
+                int nk;
+                // fetch (+ X <- T*X written back by the lane that owns the point)
+                nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
+                if (lane < nk) {
+                    const float4 p = pts[myq];
+                    q.px = p.x; q.py = p.y; q.pz = p.z;
+                    if (it > 0) {
+                        xform(s_so.T, p.x, p.y, p.z, q.px, q.py, q.pz);   // T read from LDS to keep registers free
+                        pts[myq] = make_float4(q.px, q.py, q.pz, p.w);
+                    }
+                    q.pbest = 3.402823466e38f;
+                    if (it > 0) {
+                        q.pbi = nnq[myq];
+                        const float4 q0p = tp[q.pbi];
+                        q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z);
+                    }
+                    if (it < 3) {
+                        for (int j = 0; j < c.tpl_m; j += ICP_SUB) {
+                            const float4 t = tp[j];
+                            const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                            if (d < q.pbest) { q.pbest = d; q.pbi = j; }
+                        }
+                    }
+                    q.pbest = seed_bound(q.pbest);
+                    q.poi = __float_as_int(tp[q.pbi].w);
+                }
+                if (resident) {
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+                } else {
+                    for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                        const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                        stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                        search_chunk(s_tpl, bx, c0, cn, q, nk);
+                    }
+                    staged = -1;
+                }
+                if (lane < nk) {
+                    nnq[myq] = q.pbi;
+                    const float4 qq = tp[q.pbi];
+                    const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                        S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                        for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                    }
+                    S[15] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                }
+            }
+            block_sum16(S, s_part, s_tot);
+            if (threadIdx.x == 0) {   // solve for iteration it+1 (same code as k_icp_solve)
+                float Tn[16];
+                umeyama_from_moments(s_tot, c.n, Tn);
+                float Tf[16];
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 4; ++j)
+                        Tf[4 * i + j] = ((Tn[4 * i] * s_so.Tfinal[j] + Tn[4 * i + 1] * s_so.Tfinal[4 + j]) +
+                                         Tn[4 * i + 2] * s_so.Tfinal[8 + j]) + Tn[4 * i + 3] * s_so.Tfinal[12 + j];
+                for (int i = 0; i < 16; ++i) s_so.Tfinal[i] = Tf[i];
+                s_so.iters += 1;
+                int done = 0;
+                if (s_so.iters >= prm.max_iter) {
+                    done = 1;
+                } else {
+                    const double cos_angle = 0.5 * (double)(((Tn[0] + Tn[5]) + Tn[10]) - 1.0f);
+                    const double translation_sqr = (double)((Tn[3] * Tn[3] + Tn[7] * Tn[7]) + Tn[11] * Tn[11]);
+                    if (cos_angle >= prm.rot_thr && translation_sqr <= prm.trans_eps) {
+                        done = 1;
+                    } else {
+                        const double mse = unfix(s_tot[15], FIX_SHIFT_D2) / (double)c.n;
+                        if (fabs(mse - s_so.prev_mse) < prm.abs_mse) done = 1;
+                        else if (fabs(mse - s_so.prev_mse) / s_so.prev_mse < prm.rel_mse) done = 1;
+                        s_so.prev_mse = mse;
+                    }
+                }
+                for (int i = 0; i < 16; ++i) s_so.T[i] = Tn[i];
+                s_flag[1] = done;
+            }
+            __syncthreads();
+            if (s_flag[1]) break;
+        }
+        // final X <- T*X (PCL transforms before it tests convergence), then getFitnessScore()
+        {
+            unsigned long long S[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = 0ull;
+            for (int q0 = 0; q0 < c.n; q0 += ICPT_THREADS) {
+                const int nq = min(ICPT_THREADS, c.n - q0);
+                const int myq = q0 + wave + ICPT_WAVES * lane;
+                const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                QueryRegs q;
+                q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
+                if (lane < nk) {
+                    const float4 p = pts[myq];
+                    float ox, oy, oz;
+                    xform(s_so.T, p.x, p.y, p.z, ox, oy, oz);
+                    pts[myq] = make_float4(ox, oy, oz, p.w);
+                    const float4 p0 = src0[c.src_off + myq];
+                    xform(s_so.Tfinal, p0.x, p0.y, p0.z, q.px, q.py, q.pz);
+                    q.pbi = nnq[myq];
+                    const float4 q0p = tp[q.pbi];
+                    q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z));
+                    q.poi = __float_as_int(q0p.w);
+                }
+                if (resident) {
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+                } else {
+                    for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                        const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                        stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                        search_chunk(s_tpl, bx, c0, cn, q, nk);
+                    }
+                    staged = -1;
+                }
+                if (lane < nk) S[0] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+            }
+            block_sum16(S, s_part, s_tot);
+            if (threadIdx.x == 0) {
+                s_so.done = 1;
+                s_so.converged = 1;
+                st[2 * (size_t)k] = s_so;
+                st[2 * (size_t)k + 1] = s_so;
+                accf[k] = s_tot[0];
+            }
+        }
+    }
+}
+
 // getFitnessScore(): mean squared NN distance of T_final * (original source)
 __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __restrict__ work,
                                                               const IcpCluster* __restrict__ cl,
@@ -563,6 +760,15 @@ void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const Ic
                         const float4* src0, int* nn, float* d2buf, int qslice) {
     if (n_work <= 0) return;
     hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(ICPT_THREADS), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, src0, nn, d2buf, qslice);
+}
+
+void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
+                        const float4* tpl, const float4* tlo, const float4* thi, float4* src, const float4* src0, int* nn,
+                        int* queue, int n_cu, IcpParams prm) {
+    if (ncl <= 0) return;
+    hipMemsetAsync(queue, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_icp_cluster, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
+                       src, src0, nn, queue, prm);
 }
 
 }  // namespace cd
