@@ -80,7 +80,7 @@ typedef struct cd_params {
     double cluster_tolerance;           /* 0.02 */
     /* S6 IterativeClosestPoint (icp.cpp:173-176, opd.cpp:223-226) */
     int32_t icp_max_iterations;         /* 5000 */
-    int32_t template_slot;
+    int32_t template_slot;              /* >= 0: that slot; -1: every loaded template, best fitness wins (BASELINE config 5) */
     double icp_transformation_epsilon;  /* 1e-9 */
     double icp_euclidean_fitness_epsilon; /* = icp_fitness_score param, 0.0004 (relative MSE) */
     double icp_accept_fitness;          /* acceptance test of icp.cpp:182, 0.0004 */
@@ -92,6 +92,8 @@ typedef struct cd_cluster_result {
     int32_t iterations;    /* nr_iterations_                                          */
     int32_t converged;     /* icp.hasConverged()                                      */
     int32_t accepted;      /* converged && fitness < icp_accept_fitness (icp.cpp:182) */
+    int32_t template_slot; /* slot this result was registered against (best fitness when all slots run) */
+    int32_t reserved;
     float T[16];           /* getFinalTransformation(), row-major, scene -> template  */
     double fitness;        /* getFitnessScore()                                       */
     double pose[16];       /* T.cast<double>().inverse() (icp.cpp:179), row-major     */

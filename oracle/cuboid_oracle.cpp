@@ -908,6 +908,8 @@ int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int
 
 void fill_cluster_result(const IcpOut& io, int size, double accept, cd_cluster_result* r) {
     r->size = size;
+    r->template_slot = 0;
+    r->reserved = 0;
     r->iterations = io.iterations;
     r->converged = io.converged;
     r->fitness = io.fitness;

@@ -56,6 +56,7 @@ class CdClusterResult(C.Structure):
     _fields_ = [
         ("size", C.c_int32), ("iterations", C.c_int32),
         ("converged", C.c_int32), ("accepted", C.c_int32),
+        ("template_slot", C.c_int32), ("reserved", C.c_int32),
         ("T", C.c_float * 16), ("fitness", C.c_double), ("pose", C.c_double * 16),
     ]
 

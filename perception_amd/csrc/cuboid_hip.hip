@@ -407,7 +407,7 @@ int check_params(cd_context* c, const cd_params* p) {
     if (!p) return fail(c, CD_ERR_INVALID_ARG, "params is NULL");
     if (!(p->leaf_size > 0.f)) return fail(c, CD_ERR_INVALID_ARG, "leaf_size must be > 0");
     if (p->plane_max_iterations < 0 || p->plane_max_iterations > 1000) return fail(c, CD_ERR_INVALID_ARG, "plane_max_iterations must be in [0,1000]");
-    if (p->template_slot < 0 || p->template_slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "template_slot out of range");
+    if (p->template_slot < -1 || p->template_slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "template_slot out of range");
     if (!(p->cluster_tolerance > 0.0)) return fail(c, CD_ERR_INVALID_ARG, "cluster_tolerance must be > 0");
     return CD_OK;
 }
@@ -442,29 +442,55 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     st = sync_fs(c, F);   // sync #4: n_plane, n_o, n_k, ksize, koff
     if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
-    // ICP problems
-    const int slot = p->template_slot;
+    // ICP problems.  template_slot >= 0: every cluster against that slot.  template_slot == -1: every cluster
+    // against every loaded template, one ICP pass per slot; the result with the lowest fitness is kept
+    // (ties -> lowest slot).  k_label_scatter is re-run between passes to restore the untransformed sources.
+    std::vector<int> slots;
+    if (p->template_slot >= 0) slots.push_back(p->template_slot);
+    else for (int sidx = 0; sidx < CD_MAX_TEMPLATES; ++sidx) if (c->tpl_m[sidx] > 0) slots.push_back(sidx);
+    if (slots.empty()) slots.push_back(0);
     int ncl = 0;
     std::vector<int> first_cl(F, 0);
     for (int f = 0; f < F; ++f) {
         first_cl[f] = ncl;
-        const FrameState& s = c->h_fs[f];
-        const int kk = std::min(s.n_k, KICP);
-        for (int k = 0; k < kk; ++k) {
-            IcpCluster& cl = c->h_cl[ncl++];
-            cl.src_off = f * c->N + s.koff[k];
-            cl.n = s.ksize[k];
-            cl.frame = f;
-            cl.k = k;
-            cl.tpl_off = c->tpl_off[slot];
-            cl.tpl_m = c->tpl_m[slot];
-            cl.tile0 = 0;
-            cl.pad = 0;
+        ncl += std::min(c->h_fs[f].n_k, KICP);
+    }
+    std::vector<cd_cluster_result> best((size_t)std::max(ncl, 1));
+    long long pairs = 0;
+    for (size_t si = 0; si < slots.size(); ++si) {
+        const int slot = slots[si];
+        if (si > 0) {
+            int max_no2 = 0;
+            for (int f = 0; f < F; ++f) max_no2 = std::max(max_no2, c->h_fs[f].n_o);
+            launch_label_scatter(c->stream, c->d_obj, c->N, F, c->T, std::max(1, (max_no2 + TILE - 1) / TILE), c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src);
+        }
+        int q = 0;
+        for (int f = 0; f < F; ++f) {
+            const FrameState& s = c->h_fs[f];
+            const int kk = std::min(s.n_k, KICP);
+            for (int k = 0; k < kk; ++k) {
+                IcpCluster& cl = c->h_cl[q++];
+                cl.src_off = f * c->N + s.koff[k];
+                cl.n = s.ksize[k];
+                cl.frame = f;
+                cl.k = k;
+                cl.tpl_off = c->tpl_off[slot];
+                cl.tpl_m = c->tpl_m[slot];
+                cl.tile0 = 0;
+                cl.pad = 0;
+            }
+        }
+        long long pr = 0;
+        st = stage_icp(c, ncl, p, &pr);
+        if (st) return st;
+        pairs += pr;
+        for (int k = 0; k < ncl; ++k) {
+            cd_cluster_result r;
+            fill_cluster_result(c, k, p, &r);
+            r.template_slot = slot;
+            if (si == 0 || r.fitness < best[(size_t)k].fitness) best[(size_t)k] = r;
         }
     }
-    long long pairs = 0;
-    st = stage_icp(c, ncl, p, &pairs);
-    if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // records
     long long balg = 0;
@@ -484,8 +510,8 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
         const int kk = std::min(s.n_k, KICP);
         balg += 12ll * N + 12ll * s.n_v + 12ll * s.n_v * (rounds + 3) + 4ll * s.n_v + 16ll * s.n_o + 200ll * s.n_k;
         for (int k = 0; k < kk; ++k) {
-            fill_cluster_result(c, first_cl[f] + k, p, &r.clusters[k]);
-            const long long b = 12ll * c->tpl_m[slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
+            r.clusters[k] = best[(size_t)(first_cl[f] + k)];
+            const long long b = 12ll * c->tpl_m[r.clusters[k].template_slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
             balg += b;
             c->timing.icp_algorithmic_bytes += b;
         }
@@ -843,6 +869,7 @@ int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, c
     st = stage_icp(c, 1, p, nullptr);
     if (st) return st;
     fill_cluster_result(c, 0, p, out);
+    out->template_slot = slot;
     if (aligned && n > 0) {
         std::vector<float4> tmp((size_t)n);
         HIPCHK(c, hipMemcpy(tmp.data(), c->d_src, sizeof(float4) * n, hipMemcpyDeviceToHost));

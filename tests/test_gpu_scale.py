@@ -58,6 +58,21 @@ def test_one_million_point_frame_matches_oracle(O, template):
             a, b = rg.clusters[k], ro.clusters[k]
             assert (a.size, a.iterations, a.converged) == (b.size, b.iterations, b.converged)
             assert list(a.T) == list(b.T) and a.fitness == b.fitness
+    # template_slot = -1: every cluster against every loaded template, best (lowest) fitness wins
+    prm.template_slot = -1
+    res, _, _ = ctx.process_batch(big[None], prm)
+    per = {}
+    for slot, tpl in ((0, template), (1, tall)):
+        prm.template_slot = slot
+        per[slot] = O.process_frame(big, prm, tpl)["result"]
+    rg = res[0]
+    assert rg.n_clusters == per[0].n_clusters
+    for k in range(min(rg.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+        want = min((0, 1), key=lambda s_: (per[s_].clusters[k].fitness, s_))
+        a, b = rg.clusters[k], per[want].clusters[k]
+        assert a.template_slot == want
+        assert (a.size, a.iterations, a.converged) == (b.size, b.iterations, b.converged)
+        assert list(a.T) == list(b.T) and a.fitness == b.fitness
     ctx.close()
 
 
