@@ -323,17 +323,29 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
         CD_VISIT2(m1, 64)
 #undef CD_VISIT2
 #undef CD_TAKE
-        // lexicographic (d2, original index) minimum over the wave: min distance by DPP, then the
-        // lowest original index among the lanes that hold it (almost always exactly one lane)
-        const float dmin = wave_min_f32_nonneg(lbest);
-        unsigned long long eq = __ballot(lbest == dmin);
-        int rbi = 0, roi = 0x7fffffff;
-        while (eq) {
-            const int l = __ffsll((long long)eq) - 1;
-            eq &= eq - 1;
-            const int oi_ = __builtin_amdgcn_readlane(loi, l);
-            const int bi_ = __builtin_amdgcn_readlane(lbi, l);
-            if (oi_ <= roi) { roi = oi_; rbi = bi_; }
+        // lexicographic (d2, original index) minimum over the wave.  Only lanes that beat the incoming
+        // bound can hold it; when exactly one did (the usual case once seeds are tight) it IS the answer
+        // and three v_readlane replace the reduction.  Otherwise: min distance by DPP, then the lowest
+        // original index among the lanes that hold it.
+        const unsigned long long imp = __ballot(lbest < best);
+        float dmin;
+        int rbi, roi;
+        if (__popcll(imp) == 1) {
+            const int l = __ffsll((long long)imp) - 1;
+            dmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), l));
+            rbi = __builtin_amdgcn_readlane(lbi, l);
+            roi = __builtin_amdgcn_readlane(loi, l);
+        } else {
+            dmin = wave_min_f32_nonneg(lbest);
+            unsigned long long eq = __ballot(lbest == dmin);
+            rbi = 0; roi = 0x7fffffff;
+            while (eq) {
+                const int l = __ffsll((long long)eq) - 1;
+                eq &= eq - 1;
+                const int oi_ = __builtin_amdgcn_readlane(loi, l);
+                const int bi_ = __builtin_amdgcn_readlane(lbi, l);
+                if (oi_ <= roi) { roi = oi_; rbi = bi_; }
+            }
         }
         if (lane == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
     }
