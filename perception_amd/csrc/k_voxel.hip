@@ -227,17 +227,27 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_heads_count(const uint32_t* __r
     if (threadIdx.x == 0) tile_cnt[(size_t)f * T + tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
-// One thread per voxel: walks its run in sorted order (= ascending input order inside the
-// voxel, rule C2) and forms the float32 centroid exactly as PCL does: sequential sums,
-// one division by the float count.  rgb is averaged as three float channels and re-packed.
+// One QUAD per voxel.  The 4 lanes fetch 4 consecutive members of the voxel's run at once (indices,
+// then points: members are mostly neighbouring pixels, so the 4 reads usually share a cache line),
+// and every lane of the quad replays the same strictly sequential float32 sum - ascending input
+// order inside the voxel, rule C2, exactly PCL's loop - on DPP quad broadcasts; one division by the
+// float count.  rgb is averaged as three float channels and re-packed.
+template <int I>
+__device__ __forceinline__ float quad_bcast(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true));
+}
+template <int I>
+__device__ __forceinline__ int quad_bcast_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, I | (I << 2) | (I << 4) | (I << 6), 0xf, 0xf, true);
+}
+
 __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ vals,
                                                           const float4* __restrict__ cpt, int N, int T, int rgb_on,
                                                           const FrameState* __restrict__ fs,
                                                           const int* __restrict__ tile_off, float4* __restrict__ vox) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
-    __shared__ float4 s_p[TILE];   // the tile's points in sorted order (32 KiB): the scattered gather is
-                                   // done once, by all lanes; the sequential per-voxel sums then read LDS
+    __shared__ int s_head[TILE];     // sorted positions of the voxel heads of this tile, in order
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * TILE >= n) return;
@@ -249,43 +259,56 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     int wtot = 0;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const int e = base + j * WAVE + lane;
-        if (e < n) s_p[e - tile * TILE] = cpt[fbase + v[e]];
-        bal[j] = __ballot(is_head(k, e, n));
+        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
         wtot += __popcll(bal[j]);
     }
     if (lane == 0) s_cnt[w] = wtot;
     __syncthreads();
-    int pos = tile_off[(size_t)f * T + tile];
-    for (int q = 0; q < w; ++q) pos += s_cnt[q];
+    int pos = 0, nheads = 0;
+    for (int q = 0; q < WAVES_PER_BLOCK; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if ((bal[j] >> lane) & 1ull) {
-            const int r = pos + __popcll(bal[j] & lt);
-            int e = base + j * WAVE + lane;
-            const uint32_t key = k[e];
-            float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
-            int cnt = 0;
-            const int tile_end = tile * TILE + TILE;
-            do {
-                const float4 p = e < tile_end ? s_p[e - tile * TILE] : cpt[fbase + v[e]];   // runs may spill into the next tile
-                sx = __fadd_rn(sx, p.x); sy = __fadd_rn(sy, p.y); sz = __fadd_rn(sz, p.z);
-                if (rgb_on) {
-                    const uint32_t u = __float_as_uint(p.w);
-                    cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff);
-                }
-                ++cnt; ++e;
-            } while (e < n && k[e] == key);
+        if ((bal[j] >> lane) & 1ull) s_head[pos + __popcll(bal[j] & lt)] = base + j * WAVE + lane;
+        pos += __popcll(bal[j]);
+    }
+    __syncthreads();
+    const int out0 = tile_off[(size_t)f * T + tile];
+    const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
+    for (int h = quad; h < nheads; h += BLOCK / 4) {
+        const int e0 = s_head[h];
+        const uint32_t key = k[e0];
+        float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        int cnt = 0;
+        for (int e = e0;; e += 4) {
+            const int me = e + ql;
+            const bool mine = me < n && k[me] == key;     // members of a run are contiguous in sorted order
+            float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (mine) p = cpt[fbase + v[me]];
+            const int m0 = quad_bcast_i<0>(mine), m1 = quad_bcast_i<1>(mine), m2 = quad_bcast_i<2>(mine), m3 = quad_bcast_i<3>(mine);
+#define CD_ACC(I, M)                                                                                   \
+            if (M) {                                                                                   \
+                sx = __fadd_rn(sx, quad_bcast<I>(p.x)); sy = __fadd_rn(sy, quad_bcast<I>(p.y));        \
+                sz = __fadd_rn(sz, quad_bcast<I>(p.z));                                                \
+                if (rgb_on) {                                                                          \
+                    const uint32_t u = __float_as_uint(quad_bcast<I>(p.w));                            \
+                    cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff); \
+                }                                                                                      \
+                ++cnt;                                                                                 \
+            }
+            CD_ACC(0, m0) CD_ACC(1, m1) CD_ACC(2, m2) CD_ACC(3, m3)
+#undef CD_ACC
+            if (!m3) break;    // the run ended inside this group of four (runs are contiguous)
+        }
+        if (ql == 0) {
             const float c = (float)cnt;
             uint32_t packed = 0;
             if (rgb_on) {
                 const int R = (int)__fdiv_rn(cr, c), G = (int)__fdiv_rn(cg, c), B = (int)__fdiv_rn(cb, c);
                 packed = ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
             }
-            vox[fbase + r] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
+            vox[fbase + out0 + h] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
         }
-        pos += __popcll(bal[j]);
     }
 }
 
