@@ -284,25 +284,29 @@ __device__ __forceinline__ void fetch_queries(const float4* __restrict__ tpl, in
 // Search the staged chunk for all nk queries of this wave; updates q in place.
 __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes& bx, int c0, int cn, QueryRegs& q, int nk) {
     const int lane = threadIdx.x & 63;
+#ifdef CD_STATS
     const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
+#endif
     for (int k = 0; k < nk; ++k) {
         const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
         const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
         const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
         const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-        const int bi = __builtin_amdgcn_readlane(q.pbi, k);
-        const int boi = __builtin_amdgcn_readlane(q.poi, k);
+        // Lanes start from (bound, no index): a lane can only be selected below if it beat `best`, and the
+        // seed point itself always does in the chunk that holds it.  Only when `best` is a real distance
+        // carried over from a lower chunk (c0 > 0) must ties against the carried neighbour be decided,
+        // so only then is its original index needed.
+        const int boi = c0 > 0 ? __builtin_amdgcn_readlane(q.poi, k) : 0x7fffffff;
         unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
         unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
 #ifdef CD_STATS
         if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
         float lbest = best;
-        int lbi = bi, loi = boi;
-        // Visit the surviving runs, two LDS reads in flight at a time.  The template is stored
+        int lbi = 0, loi = boi;
+        // Visit the surviving runs (1.5 per query on average, so no unrolling/padding).  The template is stored
         // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
         // order: the update is the lexicographic (d2, original index) comparison (rule C5).
-        const int pad = nruns;   // index of the all-inf pad run (its original index is INT_MAX)
 #define CD_TAKE(dd, tt, rr)                                                                     \
         {                                                                                       \
             const int oi_ = __float_as_int(tt.w);                                               \
@@ -312,12 +316,9 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
 #define CD_VISIT2(mask, base)                                                                   \
         while (mask) {                                                                          \
             const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;             \
-            const int r1 = mask ? (base) + __ffsll((long long)mask) - 1 : pad; mask &= mask - 1; \
-            const float4 t0 = s_tpl[r0 * ICP_SUB + lane], t1 = s_tpl[r1 * ICP_SUB + lane];      \
+            const float4 t0 = s_tpl[r0 * ICP_SUB + lane];                                       \
             const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                                  \
-            const float d1 = dist2(x, y, z, t1.x, t1.y, t1.z);                                  \
             CD_TAKE(d0, t0, r0)                                                                 \
-            CD_TAKE(d1, t1, r1)                                                                 \
         }
         CD_VISIT2(m0, 0)
         CD_VISIT2(m1, 64)
@@ -327,7 +328,8 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
         // bound can hold it; when exactly one did (the usual case once seeds are tight) it IS the answer
         // and three v_readlane replace the reduction.  Otherwise: min distance by DPP, then the lowest
         // original index among the lanes that hold it.
-        const unsigned long long imp = __ballot(lbest < best);
+        const unsigned long long imp = __ballot(lbest < best || (lbest == best && loi < boi));
+        if (imp == 0) continue;   // nothing in this chunk beats the carried neighbour (multi-chunk templates only)
         float dmin;
         int rbi, roi;
         if (__popcll(imp) == 1) {
