@@ -200,28 +200,37 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __rest
         int cx, cy, cz;
         cell_of(p, org, inv_cell, cx, cy, cz);
         int ri = lds_find(s_par, i);
-        for (int a = -1; a <= 1; ++a)
-            for (int b = -1; b <= 1; ++b)
-                for (int c = -1; c <= 1; ++c) {
-                    int j = s_head[cell_hash_lds(cx + a, cy + b, cz + c)];
-                    while (j >= 0) {
-                        if (j < i) {
-                            const float4 q = P[j];
-                            if (dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
-                                int rj = lds_find(s_par, j);
-                                while (ri != rj) {
-                                    const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
-                                    const int old = atomicCAS(&s_par[hi], hi, lo);   // link the larger root under the smaller
-                                    if (old == hi) { ri = lo; rj = lo; break; }
-                                    ri = lds_find(s_par, ri);                        // hi had been linked meanwhile: climb and retry
-                                    rj = lds_find(s_par, rj);
-                                }
-                                ri = ri < rj ? ri : rj;
-                            }
-                        }
-                        j = s_next[j];
-                    }
+        // Each unordered pair of neighbouring cells is examined once: the own cell (pairs j < i) and the
+        // 13 "forward" cells (dz > 0, or dz == 0 && dy > 0, or dz == dy == 0 && dx > 0), all their points.
+        // (Two different cells may share a hash bucket; a pair met twice is just a redundant union.)
+        for (int nb = 0; nb < 14; ++nb) {
+            const int code = nb == 0 ? 13 : 13 + nb;               // 13 = (0,0,0); 14..26 = forward half
+            const int a = code % 3 - 1, b = (code / 3) % 3 - 1, c = code / 9 - 1;
+            int j = s_head[cell_hash_lds(cx + a, cy + b, cz + c)];
+            while (j >= 0) {
+                int jx, jy, jz;
+                const float4 q = P[j];
+                bool take;
+                if (nb == 0) {
+                    take = j < i;
+                } else {   // the bucket may also hold points of other cells (hash collisions): keep exact cell matches only
+                    cell_of(q, org, inv_cell, jx, jy, jz);
+                    take = jx == cx + a && jy == cy + b && jz == cz + c;
                 }
+                if (take && dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+                    int rj = lds_find(s_par, j);
+                    while (ri != rj) {
+                        const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
+                        const int old = atomicCAS(&s_par[hi], hi, lo);   // link the larger root under the smaller
+                        if (old == hi) { ri = lo; rj = lo; break; }
+                        ri = lds_find(s_par, ri);                        // hi had been linked meanwhile: climb and retry
+                        rj = lds_find(s_par, rj);
+                    }
+                    ri = ri < rj ? ri : rj;
+                }
+                j = s_next[j];
+            }
+        }
     }
     __syncthreads();
     int root[CL_PER_THREAD];
