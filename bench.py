@@ -158,13 +158,15 @@ def main():
         avg_launch_ms = icp_ms / max(icp_launches, 1)
         per_launch_bytes = icp_balg / max(icp_launches / args.steps, 1)
         achieved = per_launch_bytes / (avg_launch_ms * 1e-3) / 1e9
-        # HBM bytes per k_icp_iter launch from the PMC passes (profiles/r01_pmc_traffic.json: separate
+        # HBM bytes per ICP kernel launch from the PMC passes (profiles/r01_pmc_traffic.json: separate
         # FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 x2 FETCH correction applied)
         traffic = None
+        # whole-cluster mode: ONE persistent k_icp_cluster launch per batch; sliced mode: one k_icp_iter per iteration
+        icp_kernel = "k_icp_cluster" if icp_launches == args.steps else "k_icp_iter"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if F == 256 and N == 307200:
-                traffic = pmc["kernels"]["k_icp_iter"]["hbm_bytes_per_dispatch"]
+                traffic = pmc["kernels"][icp_kernel]["hbm_bytes_per_dispatch"]
         except (OSError, KeyError, ValueError):
             pass
         out = {
@@ -176,12 +178,12 @@ def main():
                                    "parameters, 7250-point template, full chain S0-S6 + pose-record gather" % F,
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
-            "roofline": {"kernel": "k_icp_iter", "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "roofline": {"kernel": icp_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "note": "dominant kernel by time; its search is f32-VALU issue bound, not HBM bound - see icp_search and DESIGN.md section 4"},
-            "icp_search": {"kernel": "k_icp_iter", "bruteforce_equivalent_pair_tests_per_step": pairs,
+            "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
                            "note": "exact search with run-box pruning: ~1.5 of 114 template runs are visited per query, so the "
                                    "brute-force-equivalent rate is not executed work; the kernel is f32-VALU issue bound "

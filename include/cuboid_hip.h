@@ -84,6 +84,14 @@ typedef struct cd_params {
     double icp_transformation_epsilon;  /* 1e-9 */
     double icp_euclidean_fitness_epsilon; /* = icp_fitness_score param, 0.0004 (relative MSE) */
     double icp_accept_fitness;          /* acceptance test of icp.cpp:182, 0.0004 */
+    /* Optional image-space gate of cuboid_detection/src/bbox_filter.cpp (within_bbox, :30-51): a point of
+     * the extracted cloud is kept iff its projection u = (P0 x + P1 y + P2 z + P3)/w, v = ..., lies
+     * strictly inside the rectangle (x1 < u < x2, y1 < v < y2).  P = CameraInfo.P (:60-62), row-major
+     * 3x4 doubles; rectangle = the Rectangle message (:69-75).  0 disables (the launch default). */
+    double bbox_P[12];
+    int32_t bbox_enable;
+    int32_t bbox_rect[4];               /* x1, y1, x2, y2 */
+    int32_t reserved_;
 } cd_params;
 
 /* One ICP result: what icp.cpp:178-182 / opd.cpp:228-235 read back from PCL. */

@@ -446,6 +446,20 @@ int segment_plane(const float* P, int n, double thr, int max_iter, double prob, 
 }
 
 // ------------------------------------------------------------------------------------
+// bbox_filter.cpp:30-51 within_bbox(): the projection is accumulated in double (proj_matrix is
+// vector<double>, x/y/z float), stored to float, normalised by a float division, and compared
+// strictly against the int rectangle (converted to float).
+// ------------------------------------------------------------------------------------
+inline bool within_bbox(const double P[12], const int rect[4], float x, float y, float z) {
+    float u = (float)((((P[0] * x) + (P[1] * y)) + (P[2] * z)) + P[3]);
+    float v = (float)((((P[4] * x) + (P[5] * y)) + (P[6] * z)) + P[7]);
+    const float w = (float)((((P[8] * x) + (P[9] * y)) + (P[10] * z)) + P[11]);
+    u /= w;
+    v /= w;
+    return ((float)rect[0] < u && u < (float)rect[2]) && ((float)rect[1] < v && v < (float)rect[3]);
+}
+
+// ------------------------------------------------------------------------------------
 // S5  pcl::EuclideanClusterExtraction (opd.cpp:352-362)
 // neighbour predicate: (dx*dx + dy*dy) + dz*dz < (float)(tol*tol), strict.
 // ------------------------------------------------------------------------------------
@@ -1055,6 +1069,16 @@ int orc_cluster(const void* xyz, size_t stride, int n, const cd_params* prm, int
     return CD_OK;
 }
 
+int orc_bbox_filter(const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4], int32_t* out_idx, int* out_n) {
+    Cloud c{(const uint8_t*)xyz, stride, n};
+    int k = 0;
+    const int r[4] = {rect[0], rect[1], rect[2], rect[3]};
+    for (int i = 0; i < n; ++i)
+        if (within_bbox(P, r, c.x(i), c.y(i), c.z(i))) out_idx[k++] = i;
+    *out_n = k;
+    return CD_OK;
+}
+
 int orc_nn(const void* tgt, size_t tstride, int m, const void* q, size_t qstride, int n, int mode,
            int32_t* idx, float* d2) {
     std::vector<float> T, Q;
@@ -1197,6 +1221,7 @@ int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* pr
             const double v = (double)p[2];
             if (v > prm->crop2_z_max || v < prm->crop2_z_min) continue;
         }
+        if (prm->bbox_enable && !within_bbox(prm->bbox_P, prm->bbox_rect, p[0], p[1], p[2])) continue;
         obj.insert(obj.end(), p, p + 3);
     }
     const int no = (int)(obj.size() / 3);

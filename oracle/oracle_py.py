@@ -105,6 +105,16 @@ def cluster(xyz, prm, mode=1, sizes_capacity=4096):
     return labels[:n].copy(), sizes[:min(k.value, sizes_capacity)].copy(), k.value
 
 
+def bbox_filter(xyz, P, rect):
+    a, st, n = _pts(xyz)
+    Pm = np.ascontiguousarray(P, np.float64).ravel()
+    r = np.ascontiguousarray(rect, np.int32)
+    idx = np.empty(max(n, 1), np.int32)
+    cnt = C.c_int()
+    lib().orc_bbox_filter(_p(a), st, n, _p(Pm), _p(r), _p(idx), C.byref(cnt))
+    return idx[:cnt.value].copy()
+
+
 def nn(tgt, q, mode=0):
     t, ts, m = _pts(tgt)
     a, st, n = _pts(q)

@@ -49,6 +49,8 @@ class CdParams(C.Structure):
         ("icp_transformation_epsilon", C.c_double),
         ("icp_euclidean_fitness_epsilon", C.c_double),
         ("icp_accept_fitness", C.c_double),
+        ("bbox_P", C.c_double * 12), ("bbox_enable", C.c_int32), ("bbox_rect", C.c_int32 * 4),
+        ("reserved_", C.c_int32),
     ]
 
 

@@ -49,6 +49,13 @@ struct CropLimits {        // double limits folded to equivalent float compares 
     float zlo, zhi, xlo, xhi;
 };
 
+struct BBoxGate {          // bbox_filter.cpp within_bbox(), see cd_params.bbox_*
+    double P[12];
+    float rect[4];
+    int32_t enable;
+    int32_t pad;
+};
+
 struct IcpCluster {        // static description of one ICP problem (host-built)
     int32_t src_off;       // offset (points) into the ICP source buffers
     int32_t n;

@@ -225,12 +225,17 @@ int stage_extract(cd_context* c, int F, const cd_params* p) {
     for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
     const int Tv = std::max(1, (max_nv + TILE - 1) / TILE);
     const float z2lo = hm::fold_ge(p->crop2_z_min), z2hi = hm::fold_le(p->crop2_z_max);
+    BBoxGate gate;
+    std::memset(&gate, 0, sizeof(gate));
+    gate.enable = p->bbox_enable ? 1 : 0;
+    for (int i = 0; i < 12; ++i) gate.P[i] = p->bbox_P[i];
+    for (int i = 0; i < 4; ++i) gate.rect[i] = (float)p->bbox_rect[i];
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_tileB, 0, sizeof(int) * (size_t)F * T, c->stream));
-    launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, c->d_tileA, c->d_tileB);
+    launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB);
     launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_plane), FS_PITCH);
     launch_scan_tiles(c->stream, c->d_tileB, F, T, FS_FIELD(c, n_o), FS_PITCH);
-    launch_extract_scatter(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, c->d_tileA, c->d_tileB, c->d_plane_idx, c->d_obj);
+    launch_extract_scatter(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB, c->d_plane_idx, c->d_obj);
     return CD_OK;
 }
 

@@ -167,17 +167,28 @@ __global__ void __launch_bounds__(BLOCK) k_plane_cov(const float4* __restrict__ 
 }
 
 // ---- S3: flags by the refined model, ordered compaction of (plane inliers) and (objects) ----
+// bbox_filter.cpp:30-51: projection accumulated in double, stored to float, float division, strict compares
+__device__ __forceinline__ bool within_bbox(const BBoxGate& g, float x, float y, float z) {
+    float u = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(g.P[0], (double)x), __dmul_rn(g.P[1], (double)y)), __dmul_rn(g.P[2], (double)z)), g.P[3]);
+    float v = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(g.P[4], (double)x), __dmul_rn(g.P[5], (double)y)), __dmul_rn(g.P[6], (double)z)), g.P[7]);
+    const float w = (float)__dadd_rn(__dadd_rn(__dadd_rn(__dmul_rn(g.P[8], (double)x), __dmul_rn(g.P[9], (double)y)), __dmul_rn(g.P[10], (double)z)), g.P[11]);
+    u = __fdiv_rn(u, w);
+    v = __fdiv_rn(v, w);
+    return (g.rect[0] < u && u < g.rect[2]) && (g.rect[1] < v && v < g.rect[3]);
+}
+
 __device__ __forceinline__ void extract_flags(const float4& m, int have, float thr, int negative, int crop2, float z2lo,
-                                              float z2hi, const float4& p, bool& inl, bool& obj) {
+                                              float z2hi, const BBoxGate& g, const float4& p, bool& inl, bool& obj) {
     inl = plane_inlier(m, have, thr, p);
     obj = negative ? !inl : inl;
     if (obj && crop2) obj = (p.z >= z2lo) && (p.z <= z2hi);   // voxel centroids are finite
+    if (obj && g.enable) obj = within_bbox(g, p.x, p.y, p.z);
 }
 
 __global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __restrict__ vox, int N, int T,
                                                             const FrameState* __restrict__ fs,
                                                             const float4* __restrict__ model, const int* __restrict__ have,
-                                                            float thr, int negative, int crop2, float z2lo, float z2hi,
+                                                            float thr, int negative, int crop2, float z2lo, float z2hi, BBoxGate gate,
                                                             int* __restrict__ cnt_plane, int* __restrict__ cnt_obj) {
     __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -192,7 +203,7 @@ __global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __rest
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         bool inl = false, obj = false;
-        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, P[e], inl, obj);
+        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, P[e], inl, obj);
         ca += __popcll(__ballot(inl));
         cb += __popcll(__ballot(obj));
     }
@@ -207,7 +218,7 @@ __global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __rest
 __global__ void __launch_bounds__(BLOCK) k_extract_scatter(const float4* __restrict__ vox, int N, int T,
                                                            const FrameState* __restrict__ fs,
                                                            const float4* __restrict__ model, const int* __restrict__ have,
-                                                           float thr, int negative, int crop2, float z2lo, float z2hi,
+                                                           float thr, int negative, int crop2, float z2lo, float z2hi, BBoxGate gate,
                                                            const int* __restrict__ off_plane, const int* __restrict__ off_obj,
                                                            int* __restrict__ plane_idx, float4* __restrict__ obj_out) {
     __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
@@ -229,7 +240,7 @@ __global__ void __launch_bounds__(BLOCK) k_extract_scatter(const float4* __restr
         p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (e < n) {
             p[j] = P[e];
-            extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, p[j], inl, obj);
+            extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, p[j], inl, obj);
         }
         ba[j] = __ballot(inl);
         bb[j] = __ballot(obj);
@@ -265,15 +276,15 @@ void launch_plane_cov(hipStream_t s, const float4* vox, int N, int F, int Tact, 
 }
 void launch_plane_flag_count(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
                              const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
-                             float z2hi, int* cnt_plane, int* cnt_obj) {
+                             float z2hi, const BBoxGate& gate, int* cnt_plane, int* cnt_obj) {
     hipLaunchKernelGGL(k_plane_flag_count, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, T, fs, model, have, thr, negative,
-                       crop2, z2lo, z2hi, cnt_plane, cnt_obj);
+                       crop2, z2lo, z2hi, gate, cnt_plane, cnt_obj);
 }
 void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
                             const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
-                            float z2hi, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj) {
+                            float z2hi, const BBoxGate& gate, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj) {
     hipLaunchKernelGGL(k_extract_scatter, dim3(Tact, F), dim3(BLOCK), 0, s, vox, N, T, fs, model, have, thr, negative,
-                       crop2, z2lo, z2hi, off_plane, off_obj, plane_idx, obj);
+                       crop2, z2lo, z2hi, gate, off_plane, off_obj, plane_idx, obj);
 }
 
 }  // namespace cd

@@ -29,10 +29,10 @@ void launch_plane_cov(hipStream_t s, const float4* vox, int N, int F, int Tact, 
                       const int* have, float thr, unsigned long long* sums);
 void launch_plane_flag_count(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
                              const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
-                             float z2hi, int* cnt_plane, int* cnt_obj);
+                             float z2hi, const BBoxGate& gate, int* cnt_plane, int* cnt_obj);
 void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int T, int Tact, const FrameState* fs,
                             const float4* model, const int* have, float thr, int negative, int crop2, float z2lo,
-                            float z2hi, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj);
+                            float z2hi, const BBoxGate& gate, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj);
 
 // k_cluster.hip
 void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, const FrameState* fs, float inv_cell, float r2,

@@ -38,8 +38,11 @@ def test_struct_layout_matches_header():
     p = capi.CdParams()
     lib.cd_default_params(C.byref(p))
     q = capi.default_params()
-    for name, _ in capi.CdParams._fields_:
-        assert getattr(p, name) == getattr(q, name), name
+    for name, ty in capi.CdParams._fields_:
+        a, b = getattr(p, name), getattr(q, name)
+        if hasattr(a, "__len__"):
+            a, b = list(a), list(b)
+        assert a == b, name
 
 
 def test_host_side_s7_helpers_match_oracle(O):

@@ -241,6 +241,37 @@ def test_batch_cuboid_flavour_and_object_launch_params(ctx, O, template, frames4
         _same_cluster(rg.clusters[k], ro.clusters[k])
 
 
+def test_batch_with_bbox_filter_gate(ctx, O, template, frames4):
+    """bbox_filter.cpp's image-space rectangle (row 8f-4) applied to the extracted cloud: object points,
+    cluster labels and ICP results follow the oracle bit for bit, and the gate really removes points."""
+    from perception_amd import synth
+    prm = capi.default_params()
+    P = [synth.FX, 0, synth.CX, 0, 0, synth.FY, synth.CY, 0, 0, 0, 1, 0]
+    for i, v in enumerate(P):
+        prm.bbox_P[i] = v
+    base, _, _ = ctx.process_batch(np.stack(frames4, 0), prm, want_indices=True)
+    prm.bbox_enable = 1
+    for rect in ([250, 170, 400, 320], [0, 0, 640, 480], [300, 200, 301, 201]):
+        for i, v in enumerate(rect):
+            prm.bbox_rect[i] = v
+        res, pi, lb = ctx.process_batch(np.stack(frames4, 0), prm, want_indices=True)
+        for f in range(4):
+            o = O.process_frame(frames4[f], prm, template, want_clouds=True)
+            rg, ro = res[f], o["result"]
+            for k in ("status", "n_voxels", "n_plane", "n_objects", "n_clusters"):
+                assert getattr(rg, k) == getattr(ro, k), (rect, f, k)
+            assert np.array_equal(pi[f][:rg.n_plane], o["plane_inliers"])
+            assert np.array_equal(lb[f][:rg.n_objects], o["labels"])
+            for k in range(min(rg.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+                _same_cluster(rg.clusters[k], ro.clusters[k])
+            assert rg.n_plane == base[f].n_plane            # the gate acts on the extracted cloud only
+            assert rg.n_objects <= base[f].n_objects
+        if rect[0] == 250:
+            assert any(0 < res[f].n_objects < base[f].n_objects for f in range(4))
+        if rect[0] == 300:
+            assert all(res[f].n_objects < 20 for f in range(4))
+
+
 def test_batch_is_idempotent_and_frame_independent(ctx, frames4):
     """Size-independent properties: running twice gives identical bytes; a frame's record does
     not depend on its position in the batch or on its neighbours."""

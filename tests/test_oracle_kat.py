@@ -283,3 +283,40 @@ def test_icp_real_cluster_self_registration(O, prm):
     prm.icp_euclidean_fitness_epsilon = 1e-9
     st, res, _ = O.icp(X, src, prm, nn_mode=1)
     assert st == 0 and res.converged == 1 and res.fitness < 1e-10
+
+
+def _within_bbox_np(pts, P, rect):
+    """Independent restatement of bbox_filter.cpp:30-51: double accumulation, float store, float divide."""
+    P = np.asarray(P, np.float64).reshape(3, 4)
+    x, y, z = (pts[:, i].astype(np.float64) for i in range(3))
+    with np.errstate(all="ignore"):
+        uvw = [((((P[r, 0] * x) + (P[r, 1] * y)) + (P[r, 2] * z)) + P[r, 3]).astype(np.float32) for r in range(3)]
+        u = uvw[0] / uvw[2]
+        v = uvw[1] / uvw[2]
+        keep = (np.float32(rect[0]) < u) & (u < np.float32(rect[2])) & (np.float32(rect[1]) < v) & (v < np.float32(rect[3]))
+    return np.nonzero(keep)[0].astype(np.int32)
+
+
+def test_bbox_filter_predicate(O):
+    from perception_amd import synth
+    P = [synth.FX, 0, synth.CX, 0, 0, synth.FY, synth.CY, 0, 0, 0, 1, 0]
+    rect = [200, 150, 420, 330]
+    rng = np.random.default_rng(11)
+    pts = np.empty((20000, 3), np.float32)
+    pts[:, 0] = rng.uniform(-0.4, 0.4, len(pts))
+    pts[:, 1] = rng.uniform(-0.3, 0.3, len(pts))
+    pts[:, 2] = rng.uniform(0.2, 0.9, len(pts))
+    # points that project exactly onto the rectangle's edges (strict '<' drops them), z = 0 (u = inf/nan),
+    # points behind the camera, NaNs
+    z = np.float32(0.5)
+    edge = np.array([[(200 - synth.CX) / synth.FX * 0.5, 0.0, z], [0.0, (330 - synth.CY) / synth.FY * 0.5, z]], np.float32)
+    extra = np.array([[0, 0, 0], [0.1, 0.1, 0], [0.0, 0.0, -0.5], [np.nan, 0, 0.5], [0, 0, 0.5]], np.float32)
+    pts = np.concatenate([pts, edge, extra])
+    keep = O.bbox_filter(pts, P, rect)
+    assert np.array_equal(keep, _within_bbox_np(pts, P, rect))
+    assert 0 < len(keep) < len(pts)
+    assert len(pts) - 1 in keep and len(pts) - 2 not in keep and len(pts) - 5 not in keep
+    # integer-pixel projection matrix: a point that lands exactly on x1 is rejected, one ulp inside is kept
+    Pi = [100, 0, 0, 0, 0, 100, 0, 0, 0, 0, 1, 0]
+    q = np.array([[1.0, 1.5, 1.0], [np.nextafter(np.float32(1.0), np.float32(2.0)), 1.5, 1.0], [2.0, 1.5, 1.0]], np.float32)
+    assert list(O.bbox_filter(q, Pi, [100, 100, 200, 200])) == [1]
