@@ -24,6 +24,9 @@ constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses 
 constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
 constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
 constexpr int ICP_SUB = 64;                // template run length that carries one pruning box
+constexpr int ICP_TPL_LDS = 7616;          // template points resident in LDS (119 runs, 119 KiB)
+constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
+constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_QSLICE = 512;            // max ICP source points (queries) per work item / workgroup
 
 // Per-frame scalars that live on the device and are mirrored to pinned host memory.
@@ -62,7 +65,20 @@ struct IcpCluster {        // static description of one ICP problem (host-built)
     int32_t frame, k;
     int32_t tpl_off, tpl_m;
     int32_t tile0;         // first work item of this cluster
-    int32_t pad;
+    int32_t slot;          // template slot (index of its IcpGrid)
+};
+
+// Uniform grid over a template's bounding box (built by cd_set_template).  Template points are stored
+// sorted by cell id ((cz*ny + cy)*nx + cx, ties by original index), so the cells cx0..cx1 of one (cy,cz)
+// row are ONE contiguous range [start[row+cx0], start[row+cx1+1]) of stored points.
+// cell coordinate of a value v on axis a: clamp((int)floorf((v - o_a) * inv), 0, n_a - 1), float, no FMA.
+struct IcpGrid {
+    float ox, oy, oz, inv;
+    float cell;            // edge length
+    int32_t nx, ny, nz;
+    int32_t ncell;         // 0: no table (template does not fit LDS)
+    int32_t cell_off;      // offset of this template's start table in the table buffer
+    int32_t pad[2];
 };
 
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity
@@ -81,7 +97,7 @@ struct IcpWork {
 
 struct IcpParams {
     int32_t max_iter;
-    int32_t pad;
+    float grid_rc;         // lane-per-query grid search for seed balls up to grid_rc cells wide (tuning only)
     double trans_eps, rel_mse, rot_thr, abs_mse;
 };
 

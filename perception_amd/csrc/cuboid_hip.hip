@@ -46,6 +46,8 @@ struct cd_context {
         *d_rank = nullptr, *d_cand = nullptr, *d_sizes = nullptr, *d_label = nullptr;
     // templates
     float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
+    IcpGrid* d_grid = nullptr;                                    // per template slot
+    unsigned short* d_tcell = nullptr;                            // cell start tables, ICP_CELL_STRIDE entries per slot
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
     float* d_d2 = nullptr;                                        // its squared distance
     int* d_queue = nullptr;                                       // ICP work queue head
@@ -299,7 +301,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
     IcpParams ip;
     ip.max_iter = p->icp_max_iterations;
-    ip.pad = 0;
+    ip.grid_rc = 1.0f;
+    if (const char* e = std::getenv("CUBOID_ICP_GRID_RC")) ip.grid_rc = (float)std::atof(e);
     ip.trans_eps = p->icp_transformation_epsilon;
     ip.rel_mse = p->icp_euclidean_fitness_epsilon;
     ip.rot_thr = 1.0 - p->icp_transformation_epsilon;
@@ -312,7 +315,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
-        launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_src0, c->d_nn,
+        launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                            c->d_queue, c->n_cu, ip);
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         c->timing.icp_kernel_launches = 1;
@@ -482,7 +485,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
                 cl.tpl_off = c->tpl_off[slot];
                 cl.tpl_m = c->tpl_m[slot];
                 cl.tile0 = 0;
-                cl.pad = 0;
+                cl.slot = slot;
             }
         }
         long long pr = 0;
@@ -595,7 +598,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -637,6 +640,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_rank, FN) == hipSuccess && dalloc(&c->d_cand, FN) == hipSuccess && dalloc(&c->d_sizes, FN) == hipSuccess && dalloc(&c->d_label, FN) == hipSuccess;
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
+    ok = ok && dalloc(&c->d_grid, (size_t)CD_MAX_TEMPLATES) == hipSuccess && dalloc(&c->d_tcell, (size_t)CD_MAX_TEMPLATES * ICP_CELL_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)4) == hipSuccess;
     {
@@ -680,46 +684,79 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         off = c->tpl_used;
         c->tpl_used += m_pad;
     }
-    // Re-tile the template into compact patches of 64 points (k-d median splits whose left part is a
-    // multiple of 64): consecutive runs of 64 stored points then have small bounding boxes, which is
-    // what the exact pruning in k_icp_iter feeds on.  Each stored point keeps its ORIGINAL index in .w;
-    // the nearest-neighbour tie rule (lowest original index) is evaluated on that.
-    struct TP { float x, y, z; int oi; };
+    // Sort the template by the cells of a uniform grid over its bounding box (cell edge = 2 x the point
+    // spacing, enlarged until the grid has at most ICP_MAX_CELLS cells).  The lane-per-query search of
+    // k_icp.hip scans the few cell rows a query's seed ball touches; consecutive runs of 64 stored points
+    // are still spatially compact (a strip of one cell row), which is what the run boxes of the
+    // wave-per-query search feed on.  Each stored point keeps its ORIGINAL index in .w; the
+    // nearest-neighbour tie rule (lowest original index) is evaluated on that.
+    struct TP { float x, y, z; int oi; int cid; };
     std::vector<TP> tp((size_t)m);
+    float gmn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, gmx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     {
         const char* b = (const char*)xyz;
         for (int i = 0; i < m; ++i) {
             float v[3];
             std::memcpy(v, b + (size_t)i * stride, 12);
-            tp[(size_t)i] = TP{v[0], v[1], v[2], i};
+            tp[(size_t)i] = TP{v[0], v[1], v[2], i, 0};
+            for (int a = 0; a < 3; ++a)
+                if (std::isfinite(v[a])) { gmn[a] = std::fmin(gmn[a], v[a]); gmx[a] = std::fmax(gmx[a], v[a]); }
         }
+        for (int a = 0; a < 3; ++a) if (!(gmn[a] <= gmx[a])) gmn[a] = gmx[a] = 0.f;
     }
+    IcpGrid grid;
+    std::memset(&grid, 0, sizeof(grid));
+    std::vector<unsigned short> cell_start;
     {
-        std::vector<std::pair<int, int>> stack;   // [lo, hi)
-        stack.push_back({0, m});
-        while (!stack.empty()) {
-            const auto [lo, hi] = stack.back();
-            stack.pop_back();
-            const int n = hi - lo;
-            if (n <= ICP_SUB) {
-                std::sort(tp.begin() + lo, tp.begin() + hi, [](const TP& a, const TP& bb) { return a.oi < bb.oi; });
-                continue;
+        // point spacing: median nearest-neighbour distance of a sample of the points
+        std::vector<float> nn2;
+        const int step = std::max(1, m / 128);
+        for (int i = 0; i < m; i += step) {
+            float best = FLT_MAX;
+            for (int j = 0; j < m; ++j) {
+                const float dx = tp[(size_t)i].x - tp[(size_t)j].x, dy = tp[(size_t)i].y - tp[(size_t)j].y, dz = tp[(size_t)i].z - tp[(size_t)j].z;
+                const float d = dx * dx + dy * dy + dz * dz;
+                if (d > 0.f && d < best) best = d;
             }
-            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-            for (int i = lo; i < hi; ++i) {
-                const float v[3] = {tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z};
-                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
+            if (best < FLT_MAX) nn2.push_back(best);
+        }
+        float pitch = 0.002f;
+        if (!nn2.empty()) { std::nth_element(nn2.begin(), nn2.begin() + nn2.size() / 2, nn2.end()); pitch = std::sqrt(nn2[nn2.size() / 2]); }
+        float cell = std::fmax(2.0f * pitch, 1.0e-4f);
+        int nd[3];
+        for (;;) {
+            long long tot = 1;
+            for (int a = 0; a < 3; ++a) {
+                const double cnt = std::floor((double)(gmx[a] - gmn[a]) / cell) + 1.0;
+                nd[a] = cnt > 1.0e6 ? 1000000 : (int)cnt;
+                tot *= nd[a];
             }
-            int ax = 0;
-            if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
-            if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
-            int k = ((n / 2 + ICP_SUB - 1) / ICP_SUB) * ICP_SUB;
-            if (k >= n) k -= ICP_SUB;
-            auto key = [ax](const TP& t) { return ax == 0 ? t.x : (ax == 1 ? t.y : t.z); };
-            std::nth_element(tp.begin() + lo, tp.begin() + lo + k, tp.begin() + hi,
-                             [&](const TP& a, const TP& bb) { return key(a) < key(bb) || (key(a) == key(bb) && a.oi < bb.oi); });
-            stack.push_back({lo + k, hi});
-            stack.push_back({lo, lo + k});
+            if (tot <= ICP_MAX_CELLS) break;
+            cell *= 1.26f;
+        }
+        grid.ox = gmn[0]; grid.oy = gmn[1]; grid.oz = gmn[2];
+        grid.cell = cell;
+        grid.inv = 1.0f / cell;
+        grid.nx = nd[0]; grid.ny = nd[1]; grid.nz = nd[2];
+        grid.cell_off = slot * ICP_CELL_STRIDE;
+        const int ncell = nd[0] * nd[1] * nd[2];
+        auto coord = [&](float v, float o, int n) {
+            const float t = std::floor((v - o) * grid.inv);
+            return t >= (float)(n - 1) ? n - 1 : (t > 0.f ? (int)t : 0);   // NaN -> 0
+        };
+        for (int i = 0; i < m; ++i) {
+            TP& t = tp[(size_t)i];
+            t.cid = (coord(t.z, grid.oz, grid.nz) * grid.ny + coord(t.y, grid.oy, grid.ny)) * grid.nx + coord(t.x, grid.ox, grid.nx);
+        }
+        std::sort(tp.begin(), tp.end(), [](const TP& a, const TP& bb) { return a.cid < bb.cid || (a.cid == bb.cid && a.oi < bb.oi); });
+        if (m <= ICP_TPL_LDS) {
+            grid.ncell = ncell;
+            cell_start.assign((size_t)ncell + 1, 0);
+            int i = 0;
+            for (int cid = 0; cid <= ncell; ++cid) {
+                while (i < m && tp[(size_t)i].cid < cid) ++i;
+                cell_start[(size_t)cid] = (unsigned short)i;
+            }
         }
     }
     {
@@ -746,6 +783,9 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         HIPCHK(c, hipMemcpy(c->d_tlo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemcpy(c->d_thi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
     }
+    if (!cell_start.empty())
+        HIPCHK(c, hipMemcpy(c->d_tcell + grid.cell_off, cell_start.data(), sizeof(unsigned short) * cell_start.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, hipMemcpy(c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));
     c->tpl_off[slot] = off;
     c->tpl_m[slot] = m;
     return CD_OK;
@@ -870,7 +910,7 @@ int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, c
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->d_src, c->d_src0, sizeof(float4) * (size_t)std::max(n, 1), hipMemcpyDeviceToDevice, c->stream));
     IcpCluster& cl = c->h_cl[0];
-    cl.src_off = 0; cl.n = n; cl.frame = 0; cl.k = 0; cl.tpl_off = c->tpl_off[slot]; cl.tpl_m = c->tpl_m[slot]; cl.tile0 = 0; cl.pad = 0;
+    cl.src_off = 0; cl.n = n; cl.frame = 0; cl.k = 0; cl.tpl_off = c->tpl_off[slot]; cl.tpl_m = c->tpl_m[slot]; cl.tile0 = 0; cl.slot = slot;
     st = stage_icp(c, 1, p, nullptr);
     if (st) return st;
     fill_cluster_result(c, 0, p, out);

@@ -189,14 +189,14 @@ __device__ __forceinline__ void xform(const float* T, float x, float y, float z,
 // ---------------------------------------------------------------------------------------
 constexpr int ICPT_THREADS = 1024;                 // 16 waves, 4 per SIMD
 constexpr int ICPT_WAVES = ICPT_THREADS / WAVE;
-constexpr int ICPT_TPL_LDS = 7616;                 // template points resident in LDS per pass (119 runs, 119 KiB)
+constexpr int ICPT_TPL_LDS = ICP_TPL_LDS;          // template points resident in LDS per pass (119 runs, 119 KiB)
 constexpr int ICPT_IMG = ICPT_TPL_LDS + ICP_SUB;   // + one pad run
 
-#ifdef CD_STATS
-__device__ unsigned long long g_icp_stats[4];
+#if defined(CD_STATS) || defined(CD_TIMERS)
+__device__ unsigned long long g_icp_stats[16];
 extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_stats), sizeof(g_icp_stats)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)); }
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_stats), z, sizeof(z)); }
     return 0;
 }
 #endif
@@ -281,13 +281,119 @@ __device__ __forceinline__ void fetch_queries(const float4* __restrict__ tpl, in
     }
 }
 
-// Search the staged chunk for all nk queries of this wave; updates q in place.
-__device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes& bx, int c0, int cn, QueryRegs& q, int nk) {
+
+__device__ __forceinline__ unsigned long long lanes_below(int nk) { return nk >= 64 ? ~0ull : ((1ull << nk) - 1ull); }
+
+// ---------------------------------------------------------------------------------------
+// Exact nearest-neighbour search, lane-per-query over the template's uniform grid.
+//
+// Once ICP has pulled the cloud onto the template, a query's seed (its neighbour of the previous
+// iteration) is millimetres away, and the ball of that radius touches a handful of grid cells.
+// The template is stored sorted by cell (IcpGrid, common.hpp), so the cells cx0..cx1 of one
+// (cy,cz) row are one contiguous range of stored points: a lane walks the rows of its ball's
+// cell box and tests every point in them with the canonical dist2 and the lexicographic
+// (d2, original index) update.  Exactness: with bound = nextafter(d2(q, seed)) and
+//   rr = sqrt(bound)*(1+2e-6),  r_a = rr + 4e-7*|q_a| + 1e-7   (slack > rounding of q_a -+ r_a),
+// every template point p outside the cell box has |q_a - p_a| > rr on some axis a (the cell
+// coordinate is the same monotone float function on host and device), hence float
+// d2(q,p) >= rr^2*(1-5u) > bound: it can neither beat nor tie the seed.  Every point inside the
+// box is tested.  So the result equals the full scan's.  Queries whose ball is wider than
+// IcpParams::grid_rc cells (early iterations) are left to the wave-per-query search below.
+// ---------------------------------------------------------------------------------------
+
+__device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
+    const float t = floorf(__fmul_rn(__fsub_rn(v, o), inv));
+    return t >= (float)(n - 1) ? n - 1 : (t > 0.f ? (int)t : 0);
+}
+
+// q.pbest holds the seed bound on entry; `act` lanes search, the others idle through the loop.
+//
+// Row pruning: the cell box is the bounding cube of the ball, but the ball itself only reaches a few of its
+// rows.  For a row (cy,cz), e_y / e_z = distance from q to the row's slab on that axis, reduced by a slack
+// that covers every float rounding of the cell boundaries (so they are lower bounds of |q_y-p_y|, |q_z-p_z|
+// for every point p filed in the row).  A point that can still beat or tie the seed has real
+// dx^2 <= bound*(1+5u) - (dy^2+dz^2) <= rem := rr2 - e2*(1-1e-6); rem < 0 skips the row, otherwise the x-range
+// shrinks to the cells of q_x -+ sqrt(rem).
+__device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
+                                            QueryRegs& q) {
+    float lbest = q.pbest;
+    int lbi = q.pbi, loi = 0x7fffffff;
+    int y0 = 0, y1 = 0, z1 = -1, ry = 0, rz = 0;
+    float slx = 0.f, sly = 0.f, slz = 0.f, rr2 = 0.f;
+    if (act) {
+        slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
+        sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
+        slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
+        const float ryy = __fadd_rn(rr, sly), rzz = __fadd_rn(rr, slz);
+        y0 = grid_coord(__fsub_rn(q.py, ryy), g.oy, g.inv, g.ny); y1 = grid_coord(__fadd_rn(q.py, ryy), g.oy, g.inv, g.ny);
+        rz = grid_coord(__fsub_rn(q.pz, rzz), g.oz, g.inv, g.nz); z1 = grid_coord(__fadd_rn(q.pz, rzz), g.oz, g.inv, g.nz);
+        ry = y0;
+        rr2 = __fmul_rn(__fmul_rn(rr, rr), 1.0f + 1.0e-6f);
+    }
+    const float huge = 3.0e38f;
+    int i = 0, b = 0;
+    bool more = act;
+    for (;;) {
+        // A: every lane that has used up its range advances to its next row with a non-empty range
+        bool need = more && i >= b;
+        while (__ballot(need)) {
+#ifdef CD_STATS
+            { const unsigned long long nb_ = __ballot(need); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
+#endif
+            if (need) {
+                if (rz > z1) {
+                    more = false;
+                    need = false;
+                } else {
+                    // slab of row (ry, rz); the outermost cells are open-ended (they also hold whatever rounding put past the box)
+                    const float ylo = ry == 0 ? -huge : __fadd_rn(g.oy, __fmul_rn((float)ry, g.cell));
+                    const float yhi = ry == g.ny - 1 ? huge : __fadd_rn(g.oy, __fmul_rn((float)(ry + 1), g.cell));
+                    const float zlo = rz == 0 ? -huge : __fadd_rn(g.oz, __fmul_rn((float)rz, g.cell));
+                    const float zhi = rz == g.nz - 1 ? huge : __fadd_rn(g.oz, __fmul_rn((float)(rz + 1), g.cell));
+                    const float ey = fmaxf(__fsub_rn(fmaxf(__fsub_rn(ylo, q.py), __fsub_rn(q.py, yhi)), sly), 0.f);
+                    const float ez = fmaxf(__fsub_rn(fmaxf(__fsub_rn(zlo, q.pz), __fsub_rn(q.pz, zhi)), slz), 0.f);
+                    const float e2 = __fmul_rn(__fadd_rn(__fmul_rn(ey, ey), __fmul_rn(ez, ez)), 1.0f - 1.0e-6f);
+                    const float rem = __fsub_rn(rr2, e2);
+                    if (rem >= 0.f) {
+                        const float rx = __fadd_rn(__fmul_rn(__fsqrt_rn(rem), 1.0f + 1.0e-6f), slx);
+                        const int row = (rz * g.ny + ry) * g.nx;
+                        i = s_cs[row + grid_coord(__fsub_rn(q.px, rx), g.ox, g.inv, g.nx)];
+                        b = s_cs[row + grid_coord(__fadd_rn(q.px, rx), g.ox, g.inv, g.nx) + 1];
+                    }
+                    if (++ry > y1) { ry = y0; ++rz; }
+                    need = i >= b;
+                }
+            }
+        }
+        if (!__ballot(more)) break;
+        // B: test the points of the current ranges
+        while (__ballot(more && i < b)) {
+#ifdef CD_STATS
+            { const unsigned long long pb_ = __ballot(more && i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
+#endif
+            if (more && i < b) {
+                const float4 t = s_tpl[i];
+                const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                const int o = __float_as_int(t.w);
+                const bool up = (d < lbest) || (d == lbest && o < loi);
+                lbest = up ? d : lbest; lbi = up ? i : lbi; loi = up ? o : loi;
+                ++i;
+            }
+        }
+    }
+    if (act && loi != 0x7fffffff) { q.pbest = lbest; q.pbi = lbi; q.poi = loi; }
+}
+
+// Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
+__device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes& bx, int c0, int cn, QueryRegs& q,
+                                             unsigned long long todo) {
     const int lane = threadIdx.x & 63;
 #ifdef CD_STATS
     const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
 #endif
-    for (int k = 0; k < nk; ++k) {
+    while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
         const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
         const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
         const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
@@ -300,7 +406,7 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
         unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
         unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
 #ifdef CD_STATS
-        if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nruns); atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+        if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
         float lbest = best;
         int lbi = 0, loi = boi;
@@ -463,12 +569,12 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
         fetch_queries(tp, c.tpl_m, pts, nq, it > 0, it < 3, false, nullptr, nnq, q, nk);
         if (c.tpl_m <= ICPT_TPL_LDS) {
             if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
-            search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+            search_chunk(s_tpl, bx, 0, c.tpl_m, q, lanes_below(nk));
         } else {
             for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
                 const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
                 stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
-                search_chunk(s_tpl, bx, c0, cn, q, nk);
+                search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
             }
             staged = -1;
         }
@@ -544,10 +650,13 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                                                               const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
                                                               unsigned long long* __restrict__ accf,
                                                               const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                              const float4* __restrict__ thi, float4* src,
+                                                              const float4* __restrict__ thi,
+                                                              const IcpGrid* __restrict__ grids,
+                                                              const unsigned short* __restrict__ tcell, float4* src,
                                                               const float4* __restrict__ src0, int* nn, int* queue,
                                                               IcpParams prm) {
     __shared__ float4 s_tpl[ICPT_IMG];
+    __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];   // cell start table of the staged template
     __shared__ unsigned long long s_part[ICPT_WAVES][16];
     __shared__ unsigned long long s_tot[16];
     __shared__ IcpState s_so;   // the cluster's ICP state (T = current transformation_, Tfinal = accumulated)
@@ -568,11 +677,26 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
         const float4* blo = tlo + c.tpl_off / ICP_SUB;
         const float4* bhi = thi + c.tpl_off / ICP_SUB;
         const bool resident = c.tpl_m <= ICPT_TPL_LDS;
-        if (resident && staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
+        const IcpGrid g = grids[c.slot];
+        const bool grid_ok = resident && g.ncell > 0;
+        const float rmax = __fmul_rn(prm.grid_rc, g.cell);
+        if (resident && staged != c.tpl_off) {
+            __syncthreads();
+            if (grid_ok) for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
+            stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx);
+            staged = c.tpl_off;
+        }
         float4* pts = src + c.src_off;
+        const float4* pts0 = src0 + c.src_off;
         int* nnq = nn + c.src_off;
         if (threadIdx.x == 0) s_so = st[2 * (size_t)k];   // thread 0 owns and updates it
         int it = 0;
+#ifdef CD_TIMERS
+        long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define CD_PHASE(n) { const long long tn_ = clock64(); tph[n] += tn_ - tlast; tlast = tn_; }
+#else
+#define CD_PHASE(n)
+#endif
         for (;; ++it) {
             unsigned long long S[16];
 #pragma unroll
@@ -608,19 +732,30 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     q.pbest = seed_bound(q.pbest);
                     q.poi = __float_as_int(tp[q.pbi].w);
                 }
+                CD_PHASE(0)
                 if (resident) {
-                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+                    // near queries: lane-per-query walk of the grid cells their seed ball touches; the rest: wave-per-query
+                    float rr = 0.f;
+                    bool near = false;
+                    if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+                    CD_PHASE(1)
+#ifdef CD_STATS
+                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+#endif
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, __ballot(lane < nk && !near));
+                    CD_PHASE(2)
                 } else {
                     for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
                         const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
                         stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
-                        search_chunk(s_tpl, bx, c0, cn, q, nk);
+                        search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
                     }
                     staged = -1;
                 }
                 if (lane < nk) {
                     nnq[myq] = q.pbi;
-                    const float4 qq = tp[q.pbi];
+                    const float4 qq = resident ? s_tpl[q.pbi] : tp[q.pbi];
                     const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
 #pragma unroll
                     for (int a = 0; a < 3; ++a) {
@@ -632,7 +767,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     S[15] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                 }
             }
+            CD_PHASE(3)
             block_sum16(S, s_part, s_tot);
+            CD_PHASE(4)
             if (threadIdx.x == 0) {   // solve for iteration it+1 (same code as k_icp_solve)
                 float Tn[16];
                 umeyama_from_moments(s_tot, c.n, Tn);
@@ -662,8 +799,12 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                 s_flag[1] = done;
             }
             __syncthreads();
+            CD_PHASE(5)
             if (s_flag[1]) break;
         }
+#ifdef CD_TIMERS
+        if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_icp_stats[8 + i], (unsigned long long)tph[i]);
+#endif
         // final X <- T*X (PCL transforms before it tests convergence), then getFitnessScore()
         {
             unsigned long long S[16];
@@ -680,7 +821,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     float ox, oy, oz;
                     xform(s_so.T, p.x, p.y, p.z, ox, oy, oz);
                     pts[myq] = make_float4(ox, oy, oz, p.w);
-                    const float4 p0 = src0[c.src_off + myq];
+                    const float4 p0 = pts0[myq];
                     xform(s_so.Tfinal, p0.x, p0.y, p0.z, q.px, q.py, q.pz);
                     q.pbi = nnq[myq];
                     const float4 q0p = tp[q.pbi];
@@ -688,12 +829,20 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     q.poi = __float_as_int(q0p.w);
                 }
                 if (resident) {
-                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, nk);
+                    // near queries: lane-per-query walk of the grid cells their seed ball touches; the rest: wave-per-query
+                    float rr = 0.f;
+                    bool near = false;
+                    if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+#ifdef CD_STATS
+                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+#endif
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, __ballot(lane < nk && !near));
                 } else {
                     for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
                         const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
                         stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
-                        search_chunk(s_tpl, bx, c0, cn, q, nk);
+                        search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
                     }
                     staged = -1;
                 }
@@ -745,7 +894,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
         for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
             const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
             stage_chunk(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c0, cn, s_tpl, bx);
-            search_chunk(s_tpl, bx, c0, cn, q, nk);
+            search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
         }
         store_queries(q, nk, nnq, d2q);
     }
@@ -777,12 +926,13 @@ void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const Ic
 }
 
 void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
-                        const float4* tpl, const float4* tlo, const float4* thi, float4* src, const float4* src0, int* nn,
+                        const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
+                        const unsigned short* tcell, float4* src, const float4* src0, int* nn,
                         int* queue, int n_cu, IcpParams prm) {
     if (ncl <= 0) return;
     hipMemsetAsync(queue, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_icp_cluster, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
-                       src, src0, nn, queue, prm);
+                       grids, tcell, src, src0, nn, queue, prm);
 }
 
 }  // namespace cd

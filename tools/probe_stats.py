@@ -4,17 +4,19 @@ from perception_amd import capi, synth, templates
 lib = capi.load_library()
 tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
 prm = capi.default_params()
-F = 16
+F = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 fr = np.stack([synth.frame(i) for i in range(F)], 0)
 ctx = capi.Context(max_points=fr.shape[1], max_frames=F)
 ctx.set_template(0, tpl)
-out = (C.c_ulonglong * 4)()
+out = (C.c_ulonglong * 16)()
 lib.cd_debug_icp_stats(out, 1)
 res, _, _ = ctx.process_batch(fr, prm)
 lib.cd_debug_icp_stats(out, 1)
-t = ctx.timing()
-tests, proc, lanes = out[0], out[1], out[2]
-print('launches', t.icp_kernel_launches, 'icp ms', t.icp_kernel_ms)
-print("runs offered", tests, "runs visited", proc, "queries", lanes, "visited per query", proc / max(lanes, 1), "frac", proc / max(tests, 1))
-its = [r.clusters[k].iterations for r in res for k in range(r.n_clusters)]
-print('iters', its)
+o = list(out)
+passes = max(o[3] / 64, 1)
+print('queries', o[0], 'near(grid)', o[3], 'far(wave-per-query)', o[2], 'runs visited per far query', o[1] / max(o[2], 1))
+print('grid per 64-query pass: row-step iterations', o[4] / passes, '(active lanes', o[5] / max(o[4], 1), ') point-test iterations', o[6] / passes, '(active lanes', o[7] / max(o[6], 1), ')')
+print('grid per near query: row steps', o[5] / max(o[3], 1), 'points tested', o[7] / max(o[3], 1))
+ph = o[8:14]
+tot = max(sum(ph), 1)
+print('wave-0 cycles by phase: fetch %.1f%% grid %.1f%% far %.1f%% moments %.1f%% block_sum %.1f%% solve+barrier %.1f%%  (total %.3g cycles)' % tuple([100.0 * x / tot for x in ph] + [tot]))
