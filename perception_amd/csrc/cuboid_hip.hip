@@ -56,6 +56,7 @@ struct cd_context {
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
+    bool tpl_gridded[CD_MAX_TEMPLATES] = {false};                // slot has a cell start table (fits LDS)
     // ICP
     IcpCluster *d_cl = nullptr, *h_cl = nullptr;
     IcpWork *d_work = nullptr, *h_work = nullptr, *d_work2 = nullptr, *h_work2 = nullptr;
@@ -310,13 +311,21 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // Batch mode: with at least ~n_cu/2 clusters every CU can own whole clusters, so each cluster runs its
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
-    const bool whole_cluster = c->icp_mode == 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2);
+    // The pipelined variant (two clusters in flight per workgroup, no barrier in the iteration loop) needs one
+    // LDS-resident gridded template shared by every cluster of the launch; otherwise k_icp_cluster runs.
+    const bool whole_cluster = c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2);
+    bool pipe_ok = c->icp_mode != 2 && c->h_cl[0].tpl_m > 0 && c->h_cl[0].tpl_m <= ICP_TPL_LDS && c->tpl_gridded[c->h_cl[0].slot];
+    for (int k = 1; k < ncl && pipe_ok; ++k) pipe_ok = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
     if (whole_cluster) {
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
-        launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                           c->d_queue, c->n_cu, ip);
+        if (pipe_ok)
+            launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+                            c->d_queue, c->n_cu, ip);
+        else
+            launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+                               c->d_queue, c->n_cu, ip);
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         c->timing.icp_kernel_launches = 1;
         HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
@@ -651,7 +660,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
-    if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : 0);
+    if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;
@@ -788,6 +797,7 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
     HIPCHK(c, hipMemcpy(c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));
     c->tpl_off[slot] = off;
     c->tpl_m[slot] = m;
+    c->tpl_gridded[slot] = grid.ncell > 0;
     return CD_OK;
 }
 

@@ -201,6 +201,12 @@ extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef CD_TIMERS
+#define CD_PHASE(n) { const long long tn_ = clock64(); tph[n] += tn_ - tlast; tlast = tn_; }
+#else
+#define CD_PHASE(n)
+#endif
+
 __device__ __forceinline__ float next_up_nonneg(float d) { return __uint_as_float(__float_as_uint(d) + 1u); }
 __device__ __forceinline__ float seed_bound(float d0) { return d0 < 3.0e38f ? next_up_nonneg(d0) : __uint_as_float(0x7f800000u); }
 
@@ -693,9 +699,6 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
         int it = 0;
 #ifdef CD_TIMERS
         long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define CD_PHASE(n) { const long long tn_ = clock64(); tph[n] += tn_ - tlast; tlast = tn_; }
-#else
-#define CD_PHASE(n)
 #endif
         for (;; ++it) {
             unsigned long long S[16];
@@ -860,6 +863,250 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// k_icp_pipe: whole-cluster ICP with TWO clusters in flight per workgroup and no workgroup
+// barrier inside the iteration loop.
+//
+// k_icp_cluster spends about a fifth of its time in the per-iteration barrier (waves of one
+// workgroup finish their share of an iteration at different times) and another tenth in the
+// single-threaded Umeyama/SVD solve that 1023 threads wait for.  Here a workgroup owns two
+// cluster slots (same template in LDS).  Every wave walks the slots round-robin:
+//   wait until the slot's epoch says the previous step has been solved  ->  do its own share of
+//   the slot's current step (a fixed set of source points per lane, as in k_icp_cluster)  ->
+//   add its 16 fixed-point moment sums to the slot's LDS accumulators  ->  count itself arrived.
+// The wave that arrives LAST runs the solve for that step (or the fitness hand-over and the
+// refill of the slot from the global cluster queue) and bumps the epoch, while the other
+// fifteen waves are already working on the other slot.  All waves visit the same sequence of
+// (slot, epoch) steps and the slowest wave never waits for anything but a solve in progress, so
+// there is no circular wait; a slot whose queue ran dry is published as exhausted through the
+// same epoch mechanism and every wave leaves after seeing both slots exhausted.
+// Arithmetic is that of k_icp_cluster / k_icp_iter + k_icp_solve + k_icp_fitness (order-free
+// integer moment sums), so results are bit-identical.
+// ---------------------------------------------------------------------------------------
+constexpr int PIPE_SLOTS = 2;
+enum { PH_ITER = 0, PH_FIT = 1, PH_EXHAUSTED = 2, PH_FILL = 3 };
+
+struct PipeSlot {
+    IcpState so;                    // T = transformation_ of the current iteration, Tfinal = accumulated
+    unsigned long long acc[16];     // moment sums of the current step
+    int src_off, n, k;              // the cluster
+    int phase, it;
+    int arrived;                    // waves that finished their share of the current step
+    int epoch;                      // steps completed (solved) so far
+    int pad;
+};
+
+// Umeyama + convergence test of one iteration (lane 0 of the finishing wave); same code as k_icp_solve.
+__device__ __noinline__ int pipe_solve(PipeSlot* sl, const IcpParams& prm) {
+    float Tn[16];
+    umeyama_from_moments(sl->acc, sl->n, Tn);
+    float Tf[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            Tf[4 * i + j] = ((Tn[4 * i] * sl->so.Tfinal[j] + Tn[4 * i + 1] * sl->so.Tfinal[4 + j]) +
+                             Tn[4 * i + 2] * sl->so.Tfinal[8 + j]) + Tn[4 * i + 3] * sl->so.Tfinal[12 + j];
+    for (int i = 0; i < 16; ++i) sl->so.Tfinal[i] = Tf[i];
+    sl->so.iters += 1;
+    int done = 0;
+    if (sl->so.iters >= prm.max_iter) {
+        done = 1;
+    } else {
+        const double cos_angle = 0.5 * (double)(((Tn[0] + Tn[5]) + Tn[10]) - 1.0f);
+        const double translation_sqr = (double)((Tn[3] * Tn[3] + Tn[7] * Tn[7]) + Tn[11] * Tn[11]);
+        if (cos_angle >= prm.rot_thr && translation_sqr <= prm.trans_eps) {
+            done = 1;
+        } else {
+            const double mse = unfix(sl->acc[15], FIX_SHIFT_D2) / (double)sl->n;
+            if (fabs(mse - sl->so.prev_mse) < prm.abs_mse) done = 1;
+            else if (fabs(mse - sl->so.prev_mse) / sl->so.prev_mse < prm.rel_mse) done = 1;
+            sl->so.prev_mse = mse;
+        }
+    }
+    for (int i = 0; i < 16; ++i) sl->so.T[i] = Tn[i];
+    return done;
+}
+
+// next cluster from the global queue into the slot (lane 0 of the finishing wave)
+__device__ __forceinline__ void pipe_refill(PipeSlot* sl, int ncl, const int* order, const IcpCluster* cl, const IcpState* st, int* queue) {
+    for (;;) {
+        const int item = atomicAdd(queue, 1);
+        if (item >= ncl) { sl->phase = PH_EXHAUSTED; return; }
+        const int k = order[item];
+        if (st[2 * (size_t)k].done) continue;            // host pre-marked (too few points / no template)
+        const IcpCluster c = cl[k];
+        sl->src_off = c.src_off; sl->n = c.n; sl->k = k;
+        sl->so = st[2 * (size_t)k];
+        sl->phase = PH_ITER; sl->it = 0;
+        return;
+    }
+}
+
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* __restrict__ order,
+                                                           const IcpCluster* __restrict__ cl, IcpState* st,
+                                                           unsigned long long* __restrict__ accf,
+                                                           const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                           const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
+                                                           const unsigned short* __restrict__ tcell, float4* src,
+                                                           const float4* __restrict__ src0, int* nn, int* queue, IcpParams prm) {
+    __shared__ float4 s_tpl[ICPT_IMG];
+    __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
+    __shared__ PipeSlot s_slot[PIPE_SLOTS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // every cluster of one launch uses the same (LDS-resident, gridded) template - the host guarantees it
+    const IcpCluster c0 = cl[order[0]];
+    const IcpGrid g = grids[c0.slot];
+    const float4* tp = tpl + c0.tpl_off;
+    const int tpl_m = c0.tpl_m;
+    const float rmax = __fmul_rn(prm.grid_rc, g.cell);
+    RunBoxes bx;
+    for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
+    stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
+    if (threadIdx.x == 0) {
+        for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
+            PipeSlot* sl = &s_slot[sidx];
+            for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
+            sl->arrived = 0; sl->epoch = 0; sl->phase = PH_FILL; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0;
+        }
+        // slot 0 starts with a cluster; slot 1 is filled by its first finisher, after every workgroup took its first
+        pipe_refill(&s_slot[0], ncl, order, cl, st, queue);
+    }
+    __syncthreads();
+#ifdef CD_TIMERS
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+    int my_epoch0 = 0, my_epoch1 = 0;
+    bool live0 = true, live1 = true;
+    while (live0 || live1) {
+        for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
+            if (!(sidx ? live1 : live0)) continue;
+            PipeSlot* sl = &s_slot[sidx];
+            const int want = sidx ? my_epoch1 : my_epoch0;
+            while (__hip_atomic_load(&sl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(2);
+            __threadfence_block();
+            CD_PHASE(0)
+            const int phase = sl->phase;
+            if (phase == PH_EXHAUSTED) { if (sidx) live1 = false; else live0 = false; continue; }
+            unsigned long long S[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) S[i] = 0ull;
+            if (phase == PH_ITER || phase == PH_FIT) {
+                const int it = sl->it, n = sl->n;
+                float4* pts = src + sl->src_off;
+                const float4* pts0 = src0 + sl->src_off;
+                int* nnq = nn + sl->src_off;
+                for (int q0 = 0; q0 < n; q0 += ICPT_THREADS) {
+                    const int nq = min(ICPT_THREADS, n - q0);
+                    const int myq = q0 + wave + ICPT_WAVES * lane;
+                    const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                    QueryRegs q;
+                    q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
+                    if (lane < nk) {
+                        const float4 p = pts[myq];
+                        if (phase == PH_ITER) {
+                            q.px = p.x; q.py = p.y; q.pz = p.z;
+                            if (it > 0) {   // X <- T*X, written back by the lane that owns the point
+                                xform(sl->so.T, p.x, p.y, p.z, q.px, q.py, q.pz);
+                                pts[myq] = make_float4(q.px, q.py, q.pz, p.w);
+                            }
+                            q.pbest = 3.402823466e38f;
+                            if (it > 0) {
+                                q.pbi = nnq[myq];
+                                const float4 q0p = s_tpl[q.pbi];
+                                q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z);
+                            }
+                            if (it < 3) {   // coarse seeds: first point of every run
+                                for (int j = 0; j < tpl_m; j += ICP_SUB) {
+                                    const float4 t = s_tpl[j];
+                                    const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                                    if (d < q.pbest) { q.pbest = d; q.pbi = j; }
+                                }
+                            }
+                            q.pbest = seed_bound(q.pbest);
+                            q.poi = __float_as_int(s_tpl[q.pbi].w);
+                        } else {            // final X <- T*X, then getFitnessScore() of Tfinal * original source
+                            float ox, oy, oz;
+                            xform(sl->so.T, p.x, p.y, p.z, ox, oy, oz);
+                            pts[myq] = make_float4(ox, oy, oz, p.w);
+                            const float4 p0 = pts0[myq];
+                            xform(sl->so.Tfinal, p0.x, p0.y, p0.z, q.px, q.py, q.pz);
+                            q.pbi = nnq[myq];
+                            const float4 q0p = s_tpl[q.pbi];
+                            q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z));
+                            q.poi = __float_as_int(q0p.w);
+                        }
+                    }
+                    float rr = 0.f;
+                    bool near = false;
+                    if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+                    search_chunk(s_tpl, bx, 0, tpl_m, q, __ballot(lane < nk && !near));
+                    if (lane < nk) {
+                        if (phase == PH_ITER) {
+                            nnq[myq] = q.pbi;
+                            const float4 qq = s_tpl[q.pbi];
+                            const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                                S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                            }
+                            S[15] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                        } else {
+                            S[0] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                        }
+                    }
+                }
+                CD_PHASE(1)
+                // this wave's sums -> the slot's accumulators (lane k adds sum k)
+                unsigned long long mine = 0ull;
+                const int nsum = phase == PH_ITER ? 16 : 1;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    if (k < nsum) {
+                        const unsigned long long t = wave_sum_u64(S[k]);
+                        if (lane == k) mine = t;
+                    }
+                }
+                if (lane < nsum) atomicAdd(&sl->acc[lane], mine);
+                CD_PHASE(2)
+            }
+            __threadfence_block();
+            int a = 0;
+            if (lane == 0) a = atomicAdd(&sl->arrived, 1);
+            a = __builtin_amdgcn_readfirstlane(a);
+            if (a == ICPT_WAVES - 1) {   // last to arrive: finish the step for everybody
+                __threadfence_block();
+                if (lane == 0) {
+                    if (phase == PH_ITER) {
+                        if (pipe_solve(sl, prm)) sl->phase = PH_FIT; else sl->it += 1;
+                    } else {
+                        if (phase == PH_FIT) {
+                            sl->so.done = 1;
+                            sl->so.converged = 1;
+                            st[2 * (size_t)sl->k] = sl->so;
+                            st[2 * (size_t)sl->k + 1] = sl->so;
+                            accf[sl->k] = sl->acc[0];
+                        }
+                        pipe_refill(sl, ncl, order, cl, st, queue);
+                    }
+                    for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
+                    sl->arrived = 0;
+                }
+                __threadfence_block();
+                if (lane == 0) __hip_atomic_store(&sl->epoch, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                CD_PHASE(3)
+            }
+            if (sidx) ++my_epoch1; else ++my_epoch0;
+        }
+    }
+#ifdef CD_TIMERS
+    if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_icp_stats[8 + i], (unsigned long long)tph[i]);
+#endif
+}
+
 // getFitnessScore(): mean squared NN distance of T_final * (original source)
 __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __restrict__ work,
                                                               const IcpCluster* __restrict__ cl,
@@ -932,6 +1179,16 @@ void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpClust
     if (ncl <= 0) return;
     hipMemsetAsync(queue, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_icp_cluster, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
+                       grids, tcell, src, src0, nn, queue, prm);
+}
+
+void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
+                     const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
+                     const unsigned short* tcell, float4* src, const float4* src0, int* nn,
+                     int* queue, int n_cu, IcpParams prm) {
+    if (ncl <= 0) return;
+    hipMemsetAsync(queue, 0, sizeof(int), s);
+    hipLaunchKernelGGL(k_icp_pipe, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
                        grids, tcell, src, src0, nn, queue, prm);
 }
 
