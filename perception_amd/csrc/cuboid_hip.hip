@@ -46,6 +46,7 @@ struct cd_context {
         *d_rank = nullptr, *d_cand = nullptr, *d_sizes = nullptr, *d_label = nullptr;
     // templates
     float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
+    float4 *d_tplk = nullptr, *d_tlok = nullptr, *d_thik = nullptr;   // templates in k-d patch order (sliced path)
     IcpGrid* d_grid = nullptr;                                    // per template slot
     unsigned short* d_tcell = nullptr;                            // cell start tables, ICP_CELL_STRIDE entries per slot
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
@@ -354,7 +355,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int group = 8;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tpl, c->d_tlo, c->d_thi, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip);
+        for (int q = 0; q < g; ++q) launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tplk, c->d_tlok, c->d_thik, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
@@ -373,7 +374,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
-    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_src0, c->d_nn, c->d_d2, qslice);
+    launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_src0, c->d_nn, c->d_d2, qslice);
     HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -607,7 +608,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -651,6 +652,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_grid, (size_t)CD_MAX_TEMPLATES) == hipSuccess && dalloc(&c->d_tcell, (size_t)CD_MAX_TEMPLATES * ICP_CELL_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
+    ok = ok && dalloc(&c->d_tplk, (size_t)c->tpl_cap) == hipSuccess && dalloc(&c->d_tlok, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thik, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)4) == hipSuccess;
     {
         hipDeviceProp_t prop;
@@ -768,16 +770,16 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
             }
         }
     }
-    {
+    // upload one layout: the points (original index in .w) and the axis-aligned box of every run of 64
+    // consecutive STORED points (exact float min/max)
+    auto upload = [&](float4* d_pts, float4* d_lo, float4* d_hi) -> int {
         std::vector<float4> dev((size_t)m);
         for (int i = 0; i < m; ++i) {
             float w;
             std::memcpy(&w, &tp[(size_t)i].oi, 4);
             dev[(size_t)i] = make_float4(tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z, w);
         }
-        HIPCHK(c, hipMemcpy(c->d_tpl + off, dev.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice));
-    }
-    {   // axis-aligned box of every run of 64 consecutive STORED points (exact float min/max)
+        HIPCHK(c, hipMemcpy(d_pts + off, dev.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice));
         const int nrun = m_pad / ICP_SUB;
         std::vector<float4> lo((size_t)nrun), hi((size_t)nrun);
         for (int r = 0; r < nrun; ++r) {
@@ -789,9 +791,43 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
             lo[r] = make_float4(mn[0], mn[1], mn[2], 0.f);
             hi[r] = make_float4(mx[0], mx[1], mx[2], 0.f);
         }
-        HIPCHK(c, hipMemcpy(c->d_tlo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(c->d_thi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_lo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        HIPCHK(c, hipMemcpy(d_hi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        return CD_OK;
+    };
+    if (int ust = upload(c->d_tpl, c->d_tlo, c->d_thi)) return ust;   // layout 1: cell-sorted (whole-cluster kernels)
+    {
+        // Layout 2, for the sliced multi-launch path (few clusters spread over many CUs, wave-per-query search
+        // only): compact patches of 64 points from k-d median splits whose left part is a multiple of 64, so
+        // that consecutive runs of 64 stored points have the smallest boxes the run-box pruning can get.
+        std::vector<std::pair<int, int>> stack;   // [lo, hi)
+        stack.push_back({0, m});
+        while (!stack.empty()) {
+            const auto [lo, hi] = stack.back();
+            stack.pop_back();
+            const int n = hi - lo;
+            if (n <= ICP_SUB) {
+                std::sort(tp.begin() + lo, tp.begin() + hi, [](const TP& a, const TP& bb) { return a.oi < bb.oi; });
+                continue;
+            }
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int i = lo; i < hi; ++i) {
+                const float v[3] = {tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], v[a]); mx[a] = std::fmax(mx[a], v[a]); }
+            }
+            int ax = 0;
+            if (mx[1] - mn[1] > mx[ax] - mn[ax]) ax = 1;
+            if (mx[2] - mn[2] > mx[ax] - mn[ax]) ax = 2;
+            int k = ((n / 2 + ICP_SUB - 1) / ICP_SUB) * ICP_SUB;
+            if (k >= n) k -= ICP_SUB;
+            auto key = [ax](const TP& t) { return ax == 0 ? t.x : (ax == 1 ? t.y : t.z); };
+            std::nth_element(tp.begin() + lo, tp.begin() + lo + k, tp.begin() + hi,
+                             [&](const TP& a, const TP& bb) { return key(a) < key(bb) || (key(a) == key(bb) && a.oi < bb.oi); });
+            stack.push_back({lo + k, hi});
+            stack.push_back({lo, lo + k});
+        }
     }
+    if (int ust = upload(c->d_tplk, c->d_tlok, c->d_thik)) return ust;
     if (!cell_start.empty())
         HIPCHK(c, hipMemcpy(c->d_tcell + grid.cell_off, cell_start.data(), sizeof(unsigned short) * cell_start.size(), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemcpy(c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));

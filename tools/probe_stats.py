@@ -13,10 +13,11 @@ lib.cd_debug_icp_stats(out, 1)
 res, _, _ = ctx.process_batch(fr, prm)
 lib.cd_debug_icp_stats(out, 1)
 o = list(out)
-passes = max(o[3] / 64, 1)
-print('queries', o[0], 'near(grid)', o[3], 'far(wave-per-query)', o[2], 'runs visited per far query', o[1] / max(o[2], 1))
-print('grid per 64-query pass: row-step iterations', o[4] / passes, '(active lanes', o[5] / max(o[4], 1), ') point-test iterations', o[6] / passes, '(active lanes', o[7] / max(o[6], 1), ')')
-print('grid per near query: row steps', o[5] / max(o[3], 1), 'points tested', o[7] / max(o[3], 1))
+q = max(o[0], 1)
+print('queries', o[0], 'certified %.3f  grid+collect %.3f  grid plain %.3f  wave-per-query %.3f (runs visited %.2f)' % (o[3] / q, o[8] / q, o[9] / q, o[2] / q, o[1] / max(o[2], 1)))
+scans = max((o[8] + o[9]) / 64, 1)
+print('grid per 64-lane pass (if all lanes scanned): row-step iterations %.1f (active %.1f) point iterations %.1f (active %.1f)' % (o[4] / scans, o[5] / max(o[4], 1), o[6] / scans, o[7] / max(o[6], 1)))
+print('grid per scanned query: row steps %.2f points %.2f' % (o[5] / max(o[8] + o[9], 1), o[7] / max(o[8] + o[9], 1)))
 ph = o[8:14]
 tot = max(sum(ph), 1)
-print('wave-0 cycles by phase: fetch %.1f%% grid %.1f%% far %.1f%% moments %.1f%% block_sum %.1f%% solve+barrier %.1f%%  (total %.3g cycles)' % tuple([100.0 * x / tot for x in ph] + [tot]))
+print('timers (CD_TIMERS builds only): ' + ' '.join('%.1f%%' % (100.0 * x / tot) for x in ph), 'total %.3g' % tot)
