@@ -161,8 +161,10 @@ def main():
         # HBM bytes per ICP kernel launch from the PMC passes (profiles/r01_pmc_traffic.json: separate
         # FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 x2 FETCH correction applied)
         traffic = None
-        # whole-cluster mode: ONE persistent k_icp_cluster launch per batch; sliced mode: one k_icp_iter per iteration
-        icp_kernel = "k_icp_cluster" if icp_launches == args.steps else "k_icp_iter"
+        # whole-cluster mode: ONE persistent launch per batch (k_icp_pipe; k_icp_cluster when forced or when the
+        # template does not fit LDS); sliced mode: one k_icp_iter per iteration
+        whole = icp_launches == args.steps
+        icp_kernel = ("k_icp_cluster" if os.environ.get("CUBOID_ICP_MODE") == "cluster" else "k_icp_pipe") if whole else "k_icp_iter"
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             if F == 256 and N == 307200:
@@ -185,9 +187,10 @@ def main():
                          "note": "dominant kernel by time; its search is f32-VALU issue bound, not HBM bound - see icp_search and DESIGN.md section 4"},
             "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
-                           "note": "exact search with run-box pruning: ~1.5 of 114 template runs are visited per query, so the "
-                                   "brute-force-equivalent rate is not executed work; the kernel is f32-VALU issue bound "
-                                   "(SQ_ACTIVE_INST_VALU ~ 4 waves x 19 % per SIMD, profiles/)",
+                           "note": "exact search: ~77 % of the queries walk a few cells of the template's uniform grid (lane per query), "
+                                   "the rest use run-box pruning (wave per query), so the brute-force-equivalent rate is not executed "
+                                   "work; the kernel is f32-VALU issue bound (SQ_ACTIVE_INST_VALU ~ 4 waves x 18.5 % = 74 % per SIMD, "
+                                   "profiles/r01c_pmc_icp.txt)",
                            "fp32_valu_peak_tflops": FP32_VALU_PEAK_TFLOPS},
             "pipeline_hbm": {"algorithmic_bytes_per_frame": balg / F, "achieved_GBps": balg / F * value / world / 1e9,
                              "frac_of_peak": balg / F * value / world / 1e9 / HBM_PEAK_GBS},
