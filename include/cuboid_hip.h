@@ -149,6 +149,13 @@ int cd_segment_plane(cd_context* ctx, const void* xyz, size_t stride_bytes, int 
                      const cd_params* prm, float coeff[4], int32_t* inliers, int capacity,
                      int* out_n_inliers, int* out_iterations);
 
+/* bbox_filter: indices (ascending) of the points whose projection lies strictly inside the image
+ * rectangle - cuboid_detection/src/bbox_filter.cpp:30-51 (within_bbox) and :84-103 (pcl_cb builds the
+ * inlier list that its ExtractIndices keeps).  P = CameraInfo.P, row-major 3x4; rect = x1,y1,x2,y2.
+ * The same test runs fused in cd_process_batch when cd_params.bbox_enable is set. */
+int cd_bbox_filter(cd_context* ctx, const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4],
+                   int32_t* out_indices, int capacity, int* out_n);
+
 /* S5: ec.extract(cluster_indices) (opd.cpp:362).  labels[i] = cluster rank (0 = largest,
  * ties -> smaller first member index) or -1; sizes[k] for k < min(K, sizes_capacity). */
 int cd_cluster(cd_context* ctx, const void* xyz, size_t stride_bytes, int n,

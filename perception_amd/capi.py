@@ -26,7 +26,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libc
 # every symbol include/cuboid_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
-    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_cluster", "cd_icp",
+    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_batch_device", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing",
 ]
@@ -143,6 +143,7 @@ def load_library(path=None):
                                   C.c_int, ip, ip]
     lib.cd_segment_plane.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp,
                                      C.c_int, ip, ip]
+    lib.cd_bbox_filter.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, ip]
     lib.cd_cluster.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp, C.c_int, ip]
     lib.cd_icp.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(CdParams),
                            C.POINTER(CdClusterResult), vp]
@@ -172,7 +173,7 @@ def _points(a):
     """(base pointer, stride, n) of a 2-D float32 array whose rows start with x,y,z."""
     a = np.ascontiguousarray(a, dtype=np.float32) if a.dtype != np.float32 or not a.flags.c_contiguous else a
     assert a.ndim == 2 and a.shape[1] >= 3
-    return a, a.strides[0], a.shape[0]
+    return a, (a.strides[0] if a.shape[0] else 4 * a.shape[1]), a.shape[0]   # numpy reports stride 0 for empty arrays
 
 
 class Context:
@@ -230,6 +231,16 @@ class Context:
         self._check(self.lib.cd_cluster(self.h, _ptr(a), stride, n, C.byref(prm), _ptr(labels), _ptr(sizes),
                                         sizes_capacity, C.byref(k)))
         return labels[:n].copy(), sizes[:min(k.value, sizes_capacity)].copy(), k.value
+
+    def bbox_filter(self, xyz, P, rect):
+        """bbox_filter.cpp: ascending indices of the points projecting strictly inside the rectangle."""
+        a, stride, n = _points(xyz)
+        Pm = np.ascontiguousarray(P, np.float64).ravel()
+        r = np.ascontiguousarray(rect, np.int32)
+        idx = np.empty(max(n, 1), np.int32)
+        cnt = C.c_int()
+        self._check(self.lib.cd_bbox_filter(self.h, _ptr(a), stride, n, _ptr(Pm), _ptr(r), _ptr(idx), max(n, 1), C.byref(cnt)))
+        return idx[:cnt.value].copy()
 
     def icp(self, slot, src, prm, want_aligned=False):
         a, stride, n = _points(src)

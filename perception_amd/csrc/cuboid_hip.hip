@@ -222,7 +222,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
 }
 
 // S3 (+S3b).  out: d_plane_idx, d_obj, fs.n_plane, fs.n_o
-int stage_extract(cd_context* c, int F, const cd_params* p) {
+int stage_extract(cd_context* c, int F, const cd_params* p, int gate_mode = -1) {
     const int T = c->T;
     const float thr = hm::fold_ge(p->plane_distance_threshold);
     int max_nv = 0;
@@ -231,7 +231,7 @@ int stage_extract(cd_context* c, int F, const cd_params* p) {
     const float z2lo = hm::fold_ge(p->crop2_z_min), z2hi = hm::fold_le(p->crop2_z_max);
     BBoxGate gate;
     std::memset(&gate, 0, sizeof(gate));
-    gate.enable = p->bbox_enable ? 1 : 0;
+    gate.enable = gate_mode >= 0 ? gate_mode : (p->bbox_enable ? 1 : 0);
     for (int i = 0; i < 12; ++i) gate.P[i] = p->bbox_P[i];
     for (int i = 0; i < 4; ++i) gate.rect[i] = (float)p->bbox_rect[i];
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
@@ -917,6 +917,31 @@ int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const
     if (ni > 0) HIPCHK(c, hipMemcpy(inliers, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
     coeff[0] = c->h_model[0].x; coeff[1] = c->h_model[0].y; coeff[2] = c->h_model[0].z; coeff[3] = c->h_model[0].w;
     if (out_n_inliers) *out_n_inliers = ni;
+    return CD_OK;
+}
+
+int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4],
+                   int32_t* out_indices, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if ((!xyz && n > 0) || !P || !rect || !out_indices || !out_n || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (n == 0) return CD_OK;
+    int st = load_as(c, xyz, stride, n, c->d_vox, &FrameState::n_v);
+    if (st) return st;
+    cd_params q;
+    cd_default_params(&q);
+    for (int i = 0; i < 12; ++i) q.bbox_P[i] = P[i];
+    for (int i = 0; i < 4; ++i) q.bbox_rect[i] = rect[i];
+    HIPCHK(c, hipMemsetAsync(c->d_have, 0, sizeof(int), c->stream));
+    st = stage_extract(c, 1, &q, 2);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    const int ni = c->h_fs[0].n_plane;
+    if (ni > capacity) return fail(c, CD_ERR_CAPACITY, "index capacity too small");
+    if (ni > 0) HIPCHK(c, hipMemcpy(out_indices, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    *out_n = ni;
     return CD_OK;
 }
 

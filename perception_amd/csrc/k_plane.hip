@@ -179,6 +179,11 @@ __device__ __forceinline__ bool within_bbox(const BBoxGate& g, float x, float y,
 
 __device__ __forceinline__ void extract_flags(const float4& m, int have, float thr, int negative, int crop2, float z2lo,
                                               float z2hi, const BBoxGate& g, const float4& p, bool& inl, bool& obj) {
+    if (g.enable == 2) {   // cd_bbox_filter: the index output is the set of points inside the rectangle
+        inl = within_bbox(g, p.x, p.y, p.z);
+        obj = false;
+        return;
+    }
     inl = plane_inlier(m, have, thr, p);
     obj = negative ? !inl : inl;
     if (obj && crop2) obj = (p.z >= z2lo) && (p.z <= z2hi);   // voxel centroids are finite

@@ -241,6 +241,21 @@ def test_batch_cuboid_flavour_and_object_launch_params(ctx, O, template, frames4
         _same_cluster(rg.clusters[k], ro.clusters[k])
 
 
+def test_bbox_filter_stage_bit_exact(ctx, O, frames4):
+    """cd_bbox_filter (stage level, what a bbox_filter node calls) against the oracle's within_bbox."""
+    from perception_amd import synth
+    P = [synth.FX, 0, synth.CX, 0, 0, synth.FY, synth.CY, 0, 0, 0, 1, 0]
+    pts = frames4[0][:, :3].copy()
+    pts[5] = [0, 0, 0]             # w = 0: u, v = nan -> dropped
+    pts[6] = [0.1, 0.1, -0.5]      # behind the camera
+    for rect in ([200, 150, 420, 330], [0, 0, 640, 480], [10, 10, 11, 11]):
+        assert np.array_equal(ctx.bbox_filter(pts, P, rect), O.bbox_filter(pts, P, rect)), rect
+    Pi = [100, 0, 0, 0, 0, 100, 0, 0, 0, 0, 1, 0]   # exact edge: strict '<'
+    q = np.array([[1.0, 1.5, 1.0], [np.nextafter(np.float32(1.0), np.float32(2.0)), 1.5, 1.0], [2.0, 1.5, 1.0]], np.float32)
+    assert list(ctx.bbox_filter(q, Pi, [100, 100, 200, 200])) == [1]
+    assert len(ctx.bbox_filter(np.zeros((0, 3), np.float32), P, [0, 0, 1, 1])) == 0
+
+
 def test_batch_with_bbox_filter_gate(ctx, O, template, frames4):
     """bbox_filter.cpp's image-space rectangle (row 8f-4) applied to the extracted cloud: object points,
     cluster labels and ICP results follow the oracle bit for bit, and the gate really removes points."""
