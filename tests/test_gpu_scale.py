@@ -93,3 +93,50 @@ def test_capacity_and_argument_errors(template):
         ctx.process_batch(np.zeros((1, 100, 4), np.float32), prm)
     assert e.value.status == capi.CD_ERR_INVALID_ARG
     ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sliced", "cluster", "pipe"])
+def test_every_icp_driver_gives_the_same_bits(O, template, mode, monkeypatch):
+    """The three ICP drivers (sliced multi-launch, one cluster per workgroup, two-slot pipeline) and both
+    template layouts must give bit-identical results; the mode is read when the context is created."""
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    frames = np.stack([synth.frame(i) for i in (0, 5, 9)], 0)
+    prm = capi.default_params()
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, template)
+        res, _, _ = ctx.process_batch(frames, prm)
+        for f in range(len(frames)):
+            ro = O.process_frame(frames[f], prm, template)["result"]
+            assert res[f].n_clusters == ro.n_clusters
+            for k in range(min(ro.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+                a, b = res[f].clusters[k], ro.clusters[k]
+                assert (a.size, a.iterations, a.converged, a.accepted) == (b.size, b.iterations, b.converged, b.accepted), (mode, f, k)
+                assert list(a.T) == list(b.T) and a.fitness == b.fitness, (mode, f, k)
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sliced", "cluster", "pipe"])
+def test_template_larger_than_lds_in_batch_mode(O, mode, monkeypatch):
+    """A 10 700-point template does not fit the LDS image: the whole-cluster drivers fall back to the chunked
+    search of k_icp_cluster ('pipe' must notice and do the same); results still match the oracle bit for bit."""
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    big = templates.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)
+    assert len(big) > 7616
+    frames = np.stack([synth.frame(i) for i in (0, 5)], 0)
+    prm = capi.default_params()
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, big)
+        res, _, _ = ctx.process_batch(frames, prm)
+        for f in range(len(frames)):
+            ro = O.process_frame(frames[f], prm, big)["result"]
+            assert res[f].n_clusters == ro.n_clusters
+            for k in range(min(ro.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+                a, b = res[f].clusters[k], ro.clusters[k]
+                assert a.iterations == b.iterations and list(a.T) == list(b.T) and a.fitness == b.fitness, (mode, f, k)
+    finally:
+        ctx.close()
