@@ -59,3 +59,48 @@ class ShardedBatchRunner:
         res = self.process_fn(local_frames)
         local = capi.results_to_array(res).copy()
         return gather_records(local, n_frames_total, self.dist, self.device)
+
+
+class BatchPipeline:
+    """Several batches in flight on ONE GPU.
+
+    The ICP kernel is a persistent launch whose workgroups finish at very different times (a cluster needs 6...100
+    iterations), so its tail leaves CUs idle; the front end of the next batch is HBM-bound streaming work that fits
+    there.  Each in-flight batch gets its own context (stream + device arena + pinned mirrors) and its own host
+    thread - the C-ABI call is synchronous like the PCL calls it replaces, ctypes drops the GIL while it runs - and
+    the GPU overlaps the streams.  Results are identical to processing the batches one after another.
+
+    submit() returns a Future of (records uint8[F, FRAME_RESULT_BYTES], CdTiming)."""
+
+    def __init__(self, max_points, max_frames, templates_by_slot, device_id=0, inflight=2):
+        from concurrent.futures import ThreadPoolExecutor
+        self.inflight = max(1, int(inflight))
+        self.contexts = [capi.Context(max_points=max_points, max_frames=max_frames, device_id=device_id) for _ in range(self.inflight)]
+        for cx in self.contexts:
+            for slot, xyz in templates_by_slot.items():
+                cx.set_template(slot, xyz)
+        self._results = [(capi.CdFrameResult * max_frames)() for _ in range(self.inflight)]
+        self._busy = [None] * self.inflight
+        self._pool = ThreadPoolExecutor(self.inflight)
+        self._next = 0
+
+    def _run(self, i, d_ptr, stride, n_points, n_frames, prm):
+        cx, res = self.contexts[i], self._results[i]
+        cx.process_batch_device(d_ptr, stride, n_points, n_frames, prm, results=res)
+        return capi.results_to_array(res)[:n_frames].copy(), cx.timing()
+
+    def submit(self, d_ptr, stride, n_points, n_frames, prm):
+        """Queue one batch that is already resident in device memory (d_ptr: device pointer of F x N records)."""
+        i = self._next
+        self._next = (i + 1) % self.inflight
+        if self._busy[i] is not None:
+            self._busy[i].result()          # a context runs one batch at a time
+        fut = self._pool.submit(self._run, i, d_ptr, stride, n_points, n_frames, prm)
+        self._busy[i] = fut
+        return fut
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+        for cx in self.contexts:
+            cx.close()
+        self.contexts = []

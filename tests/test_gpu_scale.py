@@ -140,3 +140,28 @@ def test_template_larger_than_lds_in_batch_mode(O, mode, monkeypatch):
                 assert a.iterations == b.iterations and list(a.T) == list(b.T) and a.fitness == b.fitness, (mode, f, k)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_batches_in_flight_give_the_same_records(template):
+    """BatchPipeline: three batches submitted to two contexts overlap on the GPU; every record must be byte-identical
+    to the one a single context produces for the same batch."""
+    import torch
+    from perception_amd import batch
+    sets = [np.stack([synth.frame(i) for i in idx], 0) for idx in ((0, 1, 2), (3, 4, 5), (6, 7, 8))]
+    prm = capi.default_params()
+    N = sets[0].shape[1]
+    ctx = capi.Context(max_points=N, max_frames=3)
+    ctx.set_template(0, template)
+    want = [capi.results_to_array(ctx.process_batch(s, prm)[0]).copy() for s in sets]
+    ctx.close()
+    dev = [torch.from_numpy(s).cuda() for s in sets]
+    torch.cuda.synchronize()
+    pipe = batch.BatchPipeline(N, 3, {0: template}, inflight=2)
+    try:
+        futs = [pipe.submit(d.data_ptr(), 16, N, 3, prm) for d in dev]
+        for f, w in zip(futs, want):
+            rec, _ = f.result()
+            assert np.array_equal(rec, w)
+    finally:
+        pipe.close()
