@@ -18,9 +18,10 @@ def shard_range(n_frames, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_records(local_records, n_frames_total, dist=None, device=None):
+def gather_records(local_records, n_frames_total, dist=None, device=None, group=None):
     """All-gather per-frame records.  local_records: uint8 array (F_local, FRAME_RESULT_BYTES).
-    Returns uint8 array (n_frames_total, FRAME_RESULT_BYTES) on every rank, frame order."""
+    Returns uint8 array (n_frames_total, FRAME_RESULT_BYTES) on every rank, frame order.
+    device=None gathers host tensors (a gloo `group`); a device gathers through it (nccl = RCCL)."""
     import torch
     rec = np.ascontiguousarray(local_records, dtype=np.uint8)
     if dist is None or not dist.is_initialized():
@@ -34,7 +35,7 @@ def gather_records(local_records, n_frames_total, dist=None, device=None):
     if device is not None:
         t = t.to(device, non_blocking=False)
     out = torch.empty((world * per, capi.FRAME_RESULT_BYTES), dtype=torch.uint8, device=t.device)
-    dist.all_gather_into_tensor(out, t)
+    dist.all_gather_into_tensor(out, t, group=group)
     out = out.cpu().numpy().reshape(world, per, capi.FRAME_RESULT_BYTES)
     parts = []
     for r in range(world):
@@ -69,6 +70,8 @@ class BatchPipeline:
     there.  Each in-flight batch gets its own context (stream + device arena + pinned mirrors) and its own host
     thread - the C-ABI call is synchronous like the PCL calls it replaces, ctypes drops the GIL while it runs - and
     the GPU overlaps the streams.  Results are identical to processing the batches one after another.
+    The streams must land on different hardware queues: export GPU_MAX_HW_QUEUES=8 (HIP's default of 4 is not enough
+    once RCCL has created its own streams) before the HIP runtime starts, as bench.py does.
 
     submit() returns a Future of (records uint8[F, FRAME_RESULT_BYTES], CdTiming)."""
 

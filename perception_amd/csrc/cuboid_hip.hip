@@ -406,6 +406,13 @@ void fill_cluster_result(const cd_context* c, int k, const cd_params* p, cd_clus
         for (int i = 0; i < 16; ++i) r->pose[i] = std::numeric_limits<double>::quiet_NaN();
 }
 
+// blocking copy ordered on the context's own (non-blocking) stream: the NULL stream gives no ordering against it
+static hipError_t copy_sync(cd_context* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->stream);
+}
+
 int upload_points(cd_context* c, const void* pts, size_t stride, int n, float4* dst) {
     // host (stride) -> device float4 via the staging buffer
     if (n <= 0) return CD_OK;
@@ -541,12 +548,12 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
             if (plane_inliers) {
                 int32_t* dst = plane_inliers + (size_t)f * N;
                 std::fill(dst, dst + N, -1);
-                if (s.n_plane > 0) HIPCHK(c, hipMemcpy(dst, c->d_plane_idx + (size_t)f * c->N, sizeof(int) * s.n_plane, hipMemcpyDeviceToHost));
+                if (s.n_plane > 0) HIPCHK(c, copy_sync(c, dst, c->d_plane_idx + (size_t)f * c->N, sizeof(int) * s.n_plane, hipMemcpyDeviceToHost));
             }
             if (labels) {
                 int32_t* dst = labels + (size_t)f * N;
                 std::fill(dst, dst + N, -1);
-                if (s.n_o > 0) HIPCHK(c, hipMemcpy(dst, c->d_label + (size_t)f * c->N, sizeof(int) * s.n_o, hipMemcpyDeviceToHost));
+                if (s.n_o > 0) HIPCHK(c, copy_sync(c, dst, c->d_label + (size_t)f * c->N, sizeof(int) * s.n_o, hipMemcpyDeviceToHost));
             }
         }
     }
@@ -630,7 +637,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->F = max_frames;
     c->T = (max_points + TILE - 1) / TILE;
     const size_t N = (size_t)c->N, F = (size_t)c->F, T = (size_t)c->T, FN = F * N;
-    bool ok = hipStreamCreate(&c->stream) == hipSuccess;
+    // non-blocking: no implicit ordering against the NULL stream (torch ops, other contexts in flight)
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && dalloc(&c->d_fs, F) == hipSuccess && halloc(&c->h_fs, F) == hipSuccess;
     ok = ok && dalloc(&c->d_tileA, F * T) == hipSuccess && dalloc(&c->d_tileB, F * T) == hipSuccess && dalloc(&c->d_tileK, F * KICP * T) == hipSuccess;
@@ -672,7 +680,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
         std::vector<int> tab((size_t)RND_TABLE);
         std::mt19937 gen(12345u);
         for (auto& v : tab) v = (int)(gen() >> 1);
-        ok = hipMemcpy(c->d_rnd, tab.data(), sizeof(int) * RND_TABLE, hipMemcpyHostToDevice) == hipSuccess;
+        ok = copy_sync(c, c->d_rnd, tab.data(), sizeof(int) * RND_TABLE, hipMemcpyHostToDevice) == hipSuccess;
     }
     if (!ok) {
         cd_destroy(c);
@@ -779,7 +787,7 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
             std::memcpy(&w, &tp[(size_t)i].oi, 4);
             dev[(size_t)i] = make_float4(tp[(size_t)i].x, tp[(size_t)i].y, tp[(size_t)i].z, w);
         }
-        HIPCHK(c, hipMemcpy(d_pts + off, dev.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice));
+        HIPCHK(c, copy_sync(c, d_pts + off, dev.data(), sizeof(float4) * (size_t)m, hipMemcpyHostToDevice));
         const int nrun = m_pad / ICP_SUB;
         std::vector<float4> lo((size_t)nrun), hi((size_t)nrun);
         for (int r = 0; r < nrun; ++r) {
@@ -791,8 +799,8 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
             lo[r] = make_float4(mn[0], mn[1], mn[2], 0.f);
             hi[r] = make_float4(mx[0], mx[1], mx[2], 0.f);
         }
-        HIPCHK(c, hipMemcpy(d_lo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemcpy(d_hi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        HIPCHK(c, copy_sync(c, d_lo + off / ICP_SUB, lo.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
+        HIPCHK(c, copy_sync(c, d_hi + off / ICP_SUB, hi.data(), sizeof(float4) * nrun, hipMemcpyHostToDevice));
         return CD_OK;
     };
     if (int ust = upload(c->d_tpl, c->d_tlo, c->d_thi)) return ust;   // layout 1: cell-sorted (whole-cluster kernels)
@@ -829,8 +837,8 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
     }
     if (int ust = upload(c->d_tplk, c->d_tlok, c->d_thik)) return ust;
     if (!cell_start.empty())
-        HIPCHK(c, hipMemcpy(c->d_tcell + grid.cell_off, cell_start.data(), sizeof(unsigned short) * cell_start.size(), hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemcpy(c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));
+        HIPCHK(c, copy_sync(c, c->d_tcell + grid.cell_off, cell_start.data(), sizeof(unsigned short) * cell_start.size(), hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));
     c->tpl_off[slot] = off;
     c->tpl_m[slot] = m;
     c->tpl_gridded[slot] = grid.ncell > 0;
@@ -860,7 +868,7 @@ int cd_crop_voxel(cd_context* c, const void* points, size_t stride, int n, const
     if (s.status != CD_OK) return fail(c, s.status, "voxel grid: leaf size too small for the input extent");
     if (s.n_v > capacity) return fail(c, CD_ERR_CAPACITY, "output capacity too small");
     std::vector<float4> tmp((size_t)std::max(s.n_v, 1));
-    HIPCHK(c, hipMemcpy(tmp.data(), c->d_vox, sizeof(float4) * s.n_v, hipMemcpyDeviceToHost));
+    HIPCHK(c, copy_sync(c, tmp.data(), c->d_vox, sizeof(float4) * s.n_v, hipMemcpyDeviceToHost));
     for (int i = 0; i < s.n_v; ++i) {
         out_xyz[3 * i] = tmp[i].x; out_xyz[3 * i + 1] = tmp[i].y; out_xyz[3 * i + 2] = tmp[i].z;
         if (out_rgb) std::memcpy(&out_rgb[i], &tmp[i].w, 4);
@@ -914,7 +922,7 @@ int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const
     if (st) return st;
     const int ni = c->h_fs[0].n_plane;
     if (ni > capacity) return fail(c, CD_ERR_CAPACITY, "inlier capacity too small");
-    if (ni > 0) HIPCHK(c, hipMemcpy(inliers, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    if (ni > 0) HIPCHK(c, copy_sync(c, inliers, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
     coeff[0] = c->h_model[0].x; coeff[1] = c->h_model[0].y; coeff[2] = c->h_model[0].z; coeff[3] = c->h_model[0].w;
     if (out_n_inliers) *out_n_inliers = ni;
     return CD_OK;
@@ -940,7 +948,7 @@ int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const d
     if (st) return st;
     const int ni = c->h_fs[0].n_plane;
     if (ni > capacity) return fail(c, CD_ERR_CAPACITY, "index capacity too small");
-    if (ni > 0) HIPCHK(c, hipMemcpy(out_indices, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
+    if (ni > 0) HIPCHK(c, copy_sync(c, out_indices, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
     *out_n = ni;
     return CD_OK;
 }
@@ -960,10 +968,10 @@ int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_pa
     if (st) return st;
     st = sync_fs(c, 1);
     if (st) return st;
-    HIPCHK(c, hipMemcpy(labels, c->d_label, sizeof(int) * n, hipMemcpyDeviceToHost));
+    HIPCHK(c, copy_sync(c, labels, c->d_label, sizeof(int) * n, hipMemcpyDeviceToHost));
     const int K = c->h_fs[0].n_k;
     const int ks = std::min(K, sizes_capacity);
-    if (ks > 0) HIPCHK(c, hipMemcpy(sizes, c->d_sizes, sizeof(int) * ks, hipMemcpyDeviceToHost));
+    if (ks > 0) HIPCHK(c, copy_sync(c, sizes, c->d_sizes, sizeof(int) * ks, hipMemcpyDeviceToHost));
     if (out_k) *out_k = K;
     return CD_OK;
 }
@@ -988,7 +996,7 @@ int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, c
     out->template_slot = slot;
     if (aligned && n > 0) {
         std::vector<float4> tmp((size_t)n);
-        HIPCHK(c, hipMemcpy(tmp.data(), c->d_src, sizeof(float4) * n, hipMemcpyDeviceToHost));
+        HIPCHK(c, copy_sync(c, tmp.data(), c->d_src, sizeof(float4) * n, hipMemcpyDeviceToHost));
         for (int i = 0; i < n; ++i) { aligned[3 * i] = tmp[i].x; aligned[3 * i + 1] = tmp[i].y; aligned[3 * i + 2] = tmp[i].z; }
     }
     return c->h_st[0].status;
