@@ -91,8 +91,29 @@ typedef struct cd_params {
     double bbox_P[12];
     int32_t bbox_enable;
     int32_t bbox_rect[4];               /* x1, y1, x2, y2 */
-    int32_t reserved_;
+    /* Axis-constrained plane models of cuboid_detection/src/surface_normal_estimation.cpp:118-123
+     * (seg.setModelType / setAxis / setEpsAngle): CD_PLANE = SACMODEL_PLANE (every other call site),
+     * CD_PLANE_PERPENDICULAR = SACMODEL_PERPENDICULAR_PLANE (normal within eps of the axis),
+     * CD_PLANE_PARALLEL = SACMODEL_PARALLEL_PLANE (normal within eps of perpendicular to the axis).
+     * A hypothesis that violates the constraint scores 0 inliers but still counts as an iteration
+     * (PCL: countWithinDistance starts with isModelValid); the refined model is tested again. */
+    int32_t plane_model;
+    float plane_axis[3];
+    double plane_eps_angle;             /* radians; sne.cpp:123 uses 0.1 */
 } cd_params;
+
+enum { CD_PLANE = 0, CD_PLANE_PERPENDICULAR = 1, CD_PLANE_PARALLEL = 2 };
+
+/* Output of cd_surface_frame: what surface_normal_estimation.cpp's callback (:167-234) derives from
+ * three constrained plane fits.  Planes are in the callback's final order (most points first). */
+typedef struct cd_surface_frame_result {
+    float Rt[16];          /* row-major 4x4: columns normal[2], normal[1], normal[0], centroid (sne.cpp:218-222) */
+    float coeff[3][4];     /* plane coefficients, sorted order                                  */
+    float midpoint[3][4];  /* pcl::compute3DCentroid of each plane's points                      */
+    int32_t n_points[3];   /* points of each plane                                               */
+    int32_t iterations[3]; /* RANSAC iterations of the three fits, in FIT order                  */
+    int32_t reserved[2];
+} cd_surface_frame_result;
 
 /* One ICP result: what icp.cpp:178-182 / opd.cpp:228-235 read back from PCL. */
 typedef struct cd_cluster_result {
@@ -148,6 +169,16 @@ int cd_crop_voxel(cd_context* ctx, const void* points, size_t stride_bytes, int 
 int cd_segment_plane(cd_context* ctx, const void* xyz, size_t stride_bytes, int n,
                      const cd_params* prm, float coeff[4], int32_t* inliers, int capacity,
                      int* out_n_inliers, int* out_iterations);
+
+/* surface_normal_estimation.cpp:167-234, the whole callback: plane 0 = SACMODEL_PERPENDICULAR_PLANE to
+ * `table_normal` (the plane parallel to the table top), planes 1,2 = SACMODEL_PARALLEL_PLANE, each fitted
+ * (prm: distance threshold, iterations, optimize; eps 0.1 rad) on what the previous fit left over
+ * (getNormal, :105-165; `invert` = the node's parameter of that name), then sorted by size, made
+ * right-handed and assembled into the pose that the node broadcasts as estimated_cuboid_frame.
+ * Returns CD_ERR_NO_MODEL when one of the three fits finds no plane (the reference reads an empty
+ * coefficient vector there). */
+int cd_surface_frame(cd_context* ctx, const void* xyz, size_t stride_bytes, int n, const float table_normal[3],
+                     int invert, const cd_params* prm, cd_surface_frame_result* out);
 
 /* bbox_filter: indices (ascending) of the points whose projection lies strictly inside the image
  * rectangle - cuboid_detection/src/bbox_filter.cpp:30-51 (within_bbox) and :84-103 (pcl_cb builds the

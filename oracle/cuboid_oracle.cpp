@@ -364,6 +364,36 @@ void plane_refit(const float* P, const std::vector<int>& inl, const float model[
     out[3] = -1.0f * ((out[0] * accu[6] + out[1] * accu[7]) + out[2] * accu[8]);
 }
 
+// Axis constraint of SACMODEL_PERPENDICULAR_PLANE / SACMODEL_PARALLEL_PLANE
+// (surface_normal_estimation.cpp:118-123: setModelType, setAxis(plane_normal), setEpsAngle(0.1)).
+// PCL 1.7.2 isModelValid of the two models; float 4-vector products use the canonical (x + y) + z (w = 0).
+struct PlaneConstraint {
+    int type = CD_PLANE;
+    float axis[3] = {0, 0, 0};
+    double eps = 0.0;
+};
+bool plane_model_valid(const PlaneConstraint& pc, const float m[4]) {
+    if (pc.type == CD_PLANE || !(pc.eps > 0.0)) return true;
+    const float* ax = pc.axis;
+    if (pc.type == CD_PLANE_PERPENDICULAR) {
+        // getAngle3D(axis, coeff): float expression assigned to a double, clamped, acos
+        const float dot = (ax[0] * m[0] + ax[1] * m[1]) + ax[2] * m[2];
+        const float n1 = (ax[0] * ax[0] + ax[1] * ax[1]) + ax[2] * ax[2];
+        const float n2 = (m[0] * m[0] + m[1] * m[1]) + m[2] * m[2];
+        double rad = dot / std::sqrt(n1 * n2);
+        if (rad < -1.0) rad = -1.0;
+        else if (rad > 1.0) rad = 1.0;
+        double angle_diff = std::fabs(std::acos(rad));
+        angle_diff = std::min(angle_diff, M_PI - angle_diff);
+        return !(angle_diff > pc.eps);
+    }
+    // parallel plane: coeff.normalize(); |axis . coeff| > sin_angle_ -> invalid
+    const float nrm = std::sqrt((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]);
+    const float c[3] = {m[0] / nrm, m[1] / nrm, m[2] / nrm};
+    const float dot = (ax[0] * c[0] + ax[1] * c[1]) + ax[2] * c[2];
+    return !((double)std::fabs(dot) > std::fabs(std::sin(pc.eps)));
+}
+
 struct PlaneOut {
     float coeff[4] = {0, 0, 0, 0};
     std::vector<int> inliers;
@@ -381,7 +411,7 @@ struct PlaneTrace {
 };
 
 int segment_plane(const float* P, int n, double thr, int max_iter, double prob, bool optimize,
-                  PlaneOut& out, PlaneTrace* tr = nullptr) {
+                  PlaneOut& out, PlaneTrace* tr = nullptr, const PlaneConstraint& pc = PlaneConstraint()) {
     out.inliers.clear();
     out.iterations = 0;
     out.skipped = 0;
@@ -417,7 +447,8 @@ int segment_plane(const float* P, int n, double thr, int max_iter, double prob, 
             ++skipped;
             continue;
         }
-        const int cnt = count_within(P, n, m, thr);
+        // countWithinDistance of the constrained models starts with isModelValid
+        const int cnt = plane_model_valid(pc, m) ? count_within(P, n, m, thr) : 0;
         if (cnt > best) {
             best = cnt;
             std::memcpy(best_model, m, 16);
@@ -434,13 +465,15 @@ int segment_plane(const float* P, int n, double thr, int max_iter, double prob, 
     out.iterations = iterations;
     out.skipped = skipped;
     if (!have) return CD_ERR_NO_MODEL;
-    select_within(P, n, best_model, thr, out.inliers);
+    // selectWithinDistance of the constrained models also starts with isModelValid (-> no inliers)
+    if (plane_model_valid(pc, best_model)) select_within(P, n, best_model, thr, out.inliers);
     std::memcpy(out.coeff, best_model, 16);
     if (optimize) {
         float refined[4];
         plane_refit(P, out.inliers, best_model, refined);
         std::memcpy(out.coeff, refined, 16);
-        select_within(P, n, refined, thr, out.inliers);
+        out.inliers.clear();
+        if (plane_model_valid(pc, refined)) select_within(P, n, refined, thr, out.inliers);
     }
     return CD_OK;
 }
@@ -1000,8 +1033,12 @@ int orc_segment_plane(const void* xyz, size_t stride, int n, const cd_params* pr
     std::vector<float> P;
     gather_xyz(xyz, stride, n, P);
     PlaneOut po;
+    PlaneConstraint pc;
+    pc.type = prm->plane_model;
+    for (int a = 0; a < 3; ++a) pc.axis[a] = prm->plane_axis[a];
+    pc.eps = prm->plane_eps_angle;
     const int st = segment_plane(P.data(), n, prm->plane_distance_threshold, prm->plane_max_iterations,
-                                 prm->plane_probability, prm->plane_optimize != 0, po);
+                                 prm->plane_probability, prm->plane_optimize != 0, po, nullptr, pc);
     *out_n = 0;
     if (out_iterations) *out_iterations = po.iterations;
     if (st != CD_OK) return st;
@@ -1066,6 +1103,74 @@ int orc_cluster(const void* xyz, size_t stride, int n, const cd_params* prm, int
     std::memcpy(labels, lab.data(), (size_t)n * 4);
     for (int k = 0; k < (int)sz.size() && k < sizes_capacity; ++k) sizes[k] = sz[k];
     *out_k = (int)sz.size();
+    return CD_OK;
+}
+
+// surface_normal_estimation.cpp:167-234 (callback) with getNormal (:105-165)
+int orc_surface_frame(const void* xyz, size_t stride, int n, const float table_normal[3], int invert, const cd_params* prm,
+                      cd_surface_frame_result* out) {
+    std::memset(out, 0, sizeof(*out));
+    std::vector<float> cloud;
+    gather_xyz(xyz, stride, n, cloud);
+    float normals[3][4], mids[3][4];
+    int counts[3];
+    for (int i = 0; i < 3; ++i) {
+        PlaneConstraint pc;
+        pc.type = i == 0 ? CD_PLANE_PERPENDICULAR : CD_PLANE_PARALLEL;   // sne.cpp:188,192
+        for (int a = 0; a < 3; ++a) pc.axis[a] = table_normal[a];
+        pc.eps = 0.1;                                                    // sne.cpp:123
+        const int m = (int)(cloud.size() / 3);
+        PlaneOut po;
+        const int st = segment_plane(cloud.data(), m, prm->plane_distance_threshold, 1000, prm->plane_probability, true, po, nullptr, pc);
+        out->iterations[i] = po.iterations;
+        if (st != CD_OK) return st;
+        std::vector<char> is_inl((size_t)std::max(m, 1), 0);
+        for (int k : po.inliers) is_inl[(size_t)k] = 1;
+        std::vector<float> plane_pc, leftover;   // ExtractIndices(negative = !invert) / (negative = invert)
+        for (int k = 0; k < m; ++k) {
+            std::vector<float>& dst = ((is_inl[(size_t)k] != 0) == (invert != 0)) ? plane_pc : leftover;
+            dst.insert(dst.end(), cloud.begin() + 3 * (size_t)k, cloud.begin() + 3 * (size_t)k + 3);
+        }
+        float cs[3] = {0.f, 0.f, 0.f};           // pcl::compute3DCentroid: sequential float32 sums
+        const size_t np = plane_pc.size() / 3;
+        for (size_t k = 0; k < np; ++k)
+            for (int a = 0; a < 3; ++a) cs[a] += plane_pc[3 * k + a];
+        for (int a = 0; a < 3; ++a) mids[i][a] = cs[a] / (float)np;
+        mids[i][3] = 0.f;
+        std::memcpy(normals[i], po.coeff, 16);
+        counts[i] = (int)np;
+        cloud.swap(leftover);
+    }
+    for (int i = 0; i < 3; ++i)                  // sne.cpp:199-212
+        for (int j = i; j < 3; ++j)
+            if (counts[i] < counts[j]) {
+                std::swap(counts[i], counts[j]);
+                for (int a = 0; a < 4; ++a) {
+                    std::swap(normals[i][a], normals[j][a]);
+                    std::swap(mids[i][a], mids[j][a]);
+                }
+            }
+    const float* n0 = normals[0];
+    const float* n1 = normals[1];
+    float n2[3] = {normals[2][0], normals[2][1], normals[2][2]};
+    float cr[3];
+    cross3(n1, n0, cr);                          // sne.cpp:207: normals[2].dot(normals[1].cross(normals[0]))
+    if ((n2[0] * cr[0] + n2[1] * cr[1]) + n2[2] * cr[2] < 0.f)
+        for (int a = 0; a < 3; ++a) n2[a] = -n2[a];
+    const float d[3] = {mids[0][0] - mids[1][0], mids[0][1] - mids[1][1], mids[0][2] - mids[1][2]};
+    const float proj = (n0[0] * d[0] + n0[1] * d[1]) + n0[2] * d[2];   // sne.cpp:213
+    for (int r = 0; r < 3; ++r) {
+        out->Rt[4 * r + 0] = n2[r];
+        out->Rt[4 * r + 1] = n1[r];
+        out->Rt[4 * r + 2] = n0[r];
+        out->Rt[4 * r + 3] = mids[0][r] - proj * n0[r];
+    }
+    out->Rt[15] = 1.f;
+    for (int i = 0; i < 3; ++i) {
+        out->n_points[i] = counts[i];
+        std::memcpy(out->coeff[i], normals[i], 16);
+        std::memcpy(out->midpoint[i], mids[i], 16);
+    }
     return CD_OK;
 }
 
@@ -1199,8 +1304,12 @@ int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* pr
     if (labels)
         for (int i = 0; i < n; ++i) labels[i] = -1;
     PlaneOut po;
+    PlaneConstraint pcon;
+    pcon.type = prm->plane_model;
+    for (int a = 0; a < 3; ++a) pcon.axis[a] = prm->plane_axis[a];
+    pcon.eps = prm->plane_eps_angle;
     st = segment_plane(vo.xyz.data(), nv, prm->plane_distance_threshold, prm->plane_max_iterations,
-                       prm->plane_probability, prm->plane_optimize != 0, po);
+                       prm->plane_probability, prm->plane_optimize != 0, po, nullptr, pcon);
     res->ransac_iterations = po.iterations;
     std::vector<char> is_inl(nv, 0);
     if (st == CD_OK) {

@@ -9,7 +9,7 @@ import subprocess
 
 import numpy as np
 
-from perception_amd.capi import CdClusterResult, CdFrameResult, CdParams
+from perception_amd.capi import CdClusterResult, CdFrameResult, CdParams, CdSurfaceFrameResult
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_DIR, "liboracle.so")
@@ -103,6 +103,14 @@ def cluster(xyz, prm, mode=1, sizes_capacity=4096):
     k = C.c_int()
     lib().orc_cluster(_p(a), st, n, C.byref(prm), mode, _p(labels), _p(sizes), sizes_capacity, C.byref(k))
     return labels[:n].copy(), sizes[:min(k.value, sizes_capacity)].copy(), k.value
+
+
+def surface_frame(xyz, table_normal, prm, invert=True):
+    a, st, n = _pts(xyz)
+    tn = np.ascontiguousarray(table_normal, np.float32)
+    res = CdSurfaceFrameResult()
+    s = lib().orc_surface_frame(_p(a), st, n, _p(tn), 1 if invert else 0, C.byref(prm), C.byref(res))
+    return s, res
 
 
 def bbox_filter(xyz, P, rect):

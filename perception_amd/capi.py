@@ -26,10 +26,18 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libc
 # every symbol include/cuboid_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
-    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_bbox_filter", "cd_cluster", "cd_icp",
+    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_batch_device", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing",
 ]
+
+
+CD_PLANE, CD_PLANE_PERPENDICULAR, CD_PLANE_PARALLEL = 0, 1, 2
+
+
+class CdSurfaceFrameResult(C.Structure):
+    _fields_ = [("Rt", C.c_float * 16), ("coeff", (C.c_float * 4) * 3), ("midpoint", (C.c_float * 4) * 3),
+                ("n_points", C.c_int32 * 3), ("iterations", C.c_int32 * 3), ("reserved", C.c_int32 * 2)]
 
 
 class CdParams(C.Structure):
@@ -50,7 +58,7 @@ class CdParams(C.Structure):
         ("icp_euclidean_fitness_epsilon", C.c_double),
         ("icp_accept_fitness", C.c_double),
         ("bbox_P", C.c_double * 12), ("bbox_enable", C.c_int32), ("bbox_rect", C.c_int32 * 4),
-        ("reserved_", C.c_int32),
+        ("plane_model", C.c_int32), ("plane_axis", C.c_float * 3), ("plane_eps_angle", C.c_double),
     ]
 
 
@@ -143,6 +151,7 @@ def load_library(path=None):
                                   C.c_int, ip, ip]
     lib.cd_segment_plane.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp,
                                      C.c_int, ip, ip]
+    lib.cd_surface_frame.argtypes = [vp, vp, C.c_size_t, C.c_int, f32p, C.c_int, C.POINTER(CdParams), C.POINTER(CdSurfaceFrameResult)]
     lib.cd_bbox_filter.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, ip]
     lib.cd_cluster.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp, C.c_int, ip]
     lib.cd_icp.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(CdParams),
@@ -231,6 +240,16 @@ class Context:
         self._check(self.lib.cd_cluster(self.h, _ptr(a), stride, n, C.byref(prm), _ptr(labels), _ptr(sizes),
                                         sizes_capacity, C.byref(k)))
         return labels[:n].copy(), sizes[:min(k.value, sizes_capacity)].copy(), k.value
+
+    def surface_frame(self, xyz, table_normal, prm, invert=True):
+        """surface_normal_estimation.cpp's callback: three axis-constrained plane fits -> pose of the cuboid frame."""
+        a, stride, n = _points(xyz)
+        tn = np.ascontiguousarray(table_normal, np.float32)
+        res = CdSurfaceFrameResult()
+        st = self.lib.cd_surface_frame(self.h, _ptr(a), stride, n, tn.ctypes.data_as(C.POINTER(C.c_float)), 1 if invert else 0,
+                                       C.byref(prm), C.byref(res))
+        self._check(st, ok=(CD_OK, CD_ERR_NO_MODEL))
+        return st, res
 
     def bbox_filter(self, xyz, P, rect):
         """bbox_filter.cpp: ascending indices of the points projecting strictly inside the rectangle."""

@@ -108,7 +108,7 @@ private:
     static cd_params defaults() { cd_params p; cd_default_params(&p); return p; }
 };
 
-enum { SACMODEL_PLANE = 0 };
+enum { SACMODEL_PLANE = 0, SACMODEL_PARALLEL_PLANE = 15, SACMODEL_PERPENDICULAR_PLANE = 9 };   // PCL's pcl::SacModel values
 enum { SAC_RANSAC = 0 };
 
 // gps.cpp:78-93: pcl::SACSegmentation<PointXYZ>
@@ -117,7 +117,15 @@ class SACSegmentation {
 public:
     SACSegmentation() { cd_default_params(&prm_); }
     void setOptimizeCoefficients(bool b) { prm_.plane_optimize = b ? 1 : 0; }
-    void setModelType(int m) { if (m != SACMODEL_PLANE) throw std::invalid_argument("only SACMODEL_PLANE"); }
+    // SACMODEL_PLANE (gps.cpp:86), SACMODEL_PERPENDICULAR_PLANE / SACMODEL_PARALLEL_PLANE (sne.cpp:120,188,192)
+    void setModelType(int m) {
+        if (m == SACMODEL_PLANE) prm_.plane_model = CD_PLANE;
+        else if (m == SACMODEL_PERPENDICULAR_PLANE) prm_.plane_model = CD_PLANE_PERPENDICULAR;
+        else if (m == SACMODEL_PARALLEL_PLANE) prm_.plane_model = CD_PLANE_PARALLEL;
+        else throw std::invalid_argument("unsupported SAC model");
+    }
+    template <class Vec3> void setAxis(const Vec3& ax) { for (int i = 0; i < 3; ++i) prm_.plane_axis[i] = (float)ax[i]; }   // sne.cpp:122
+    void setEpsAngle(double ea) { prm_.plane_eps_angle = ea; }                                                                 // sne.cpp:123
     void setMethodType(int m) { if (m != SAC_RANSAC) throw std::invalid_argument("only SAC_RANSAC"); }
     void setMaxIterations(int n) { prm_.plane_max_iterations = n; }
     void setDistanceThreshold(double t) { prm_.plane_distance_threshold = t; }

@@ -187,6 +187,14 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
         for (int f = 0; f < F; ++f) {
             if (!c->h_active[f]) continue;
             const FrameState& s = c->h_fs[f];
+            if (p->plane_model != CD_PLANE) {   // constrained models: a hypothesis off the axis constraint scores 0 inliers
+                for (int h = rep[f].pos; h < s.n_hyp; ++h) {
+                    const float4 m = c->h_models[(size_t)f * MAX_HYP + h];
+                    const float mm[4] = {m.x, m.y, m.z, m.w};
+                    if (c->h_valid[(size_t)f * MAX_HYP + h] && !hm::plane_model_valid(p->plane_model, mm, p->plane_axis, p->plane_eps_angle))
+                        c->h_counts[(size_t)f * MAX_HYP + h] = 0;
+                }
+            }
             const bool fin = rep[f].consume(c->h_counts + (size_t)f * MAX_HYP, c->h_valid + (size_t)f * MAX_HYP, s.n_hyp, std::max(1, s.n_v),
                                             p->plane_max_iterations, p->plane_probability, s.sampler_exhausted != 0 || h_target >= h_cap);
             if (fin) c->h_active[f] = 0; else all_done = false;
@@ -202,8 +210,18 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
         c->h_model[f] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c->h_have[f]) c->h_model[f] = c->h_models[(size_t)f * MAX_HYP + rep[f].best_h];
     }
+    // selectWithinDistance of a constrained model returns nothing when the model violates the constraint: the
+    // device then sees "no model" (h_active doubles as the pinned staging copy), the host keeps reporting it
+    auto upload_have = [&]() -> int {
+        for (int f = 0; f < F; ++f) {
+            const float mm[4] = {c->h_model[f].x, c->h_model[f].y, c->h_model[f].z, c->h_model[f].w};
+            c->h_active[f] = c->h_have[f] && hm::plane_model_valid(p->plane_model, mm, p->plane_axis, p->plane_eps_angle) ? 1 : 0;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+        return CD_OK;
+    };
     HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_have, c->h_have, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+    if (int st = upload_have()) return st;
     if (p->plane_optimize) {
         HIPCHK(c, hipMemsetAsync(c->d_sums, 0, sizeof(unsigned long long) * 10 * F, c->stream));
         launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums);
@@ -216,6 +234,10 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
             c->h_model[f] = make_float4(out[0], out[1], out[2], out[3]);
         }
         HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
+        if (p->plane_model != CD_PLANE) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));   // h_active is about to be rewritten
+            if (int st = upload_have()) return st;
+        }
     }
     (void)T;
     return CD_OK;
@@ -434,6 +456,7 @@ int check_params(cd_context* c, const cd_params* p) {
     if (p->plane_max_iterations < 0 || p->plane_max_iterations > 1000) return fail(c, CD_ERR_INVALID_ARG, "plane_max_iterations must be in [0,1000]");
     if (p->template_slot < -1 || p->template_slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "template_slot out of range");
     if (!(p->cluster_tolerance > 0.0)) return fail(c, CD_ERR_INVALID_ARG, "cluster_tolerance must be > 0");
+    if (p->plane_model < CD_PLANE || p->plane_model > CD_PLANE_PARALLEL) return fail(c, CD_ERR_INVALID_ARG, "plane_model out of range");
     return CD_OK;
 }
 
@@ -589,6 +612,8 @@ void cd_default_params(cd_params* p) {
     p->cluster_tolerance = 0.02;                         // opd.cpp:356
     p->icp_max_iterations = 5000;                        // icp.cpp:173
     p->template_slot = 0;
+    p->plane_model = CD_PLANE;
+    p->plane_eps_angle = 0.0;
     p->icp_transformation_epsilon = 1e-9;                // icp.cpp:174
     p->icp_euclidean_fitness_epsilon = 0.0004;           // icp.cpp:176 + launch:42
     p->icp_accept_fitness = 0.0004;                      // icp.cpp:182
@@ -925,6 +950,81 @@ int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const
     if (ni > 0) HIPCHK(c, copy_sync(c, inliers, c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
     coeff[0] = c->h_model[0].x; coeff[1] = c->h_model[0].y; coeff[2] = c->h_model[0].z; coeff[3] = c->h_model[0].w;
     if (out_n_inliers) *out_n_inliers = ni;
+    return CD_OK;
+}
+
+// surface_normal_estimation.cpp:167-234.  The three constrained fits run on the device (cd_segment_plane's
+// stages); the bookkeeping between them (ExtractIndices, pcl::compute3DCentroid - a sequential float32 sum -,
+// the size sort, the handedness flip and the pose assembly) is the callback's own host code.
+int cd_surface_frame(cd_context* c, const void* xyz, size_t stride, int n, const float table_normal[3], int invert,
+                     const cd_params* p, cd_surface_frame_result* out) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    int st = check_params(c, p);
+    if (st) return st;
+    if ((!xyz && n > 0) || !table_normal || !out || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    std::memset(out, 0, sizeof(*out));
+    struct P3 { float x, y, z; };
+    std::vector<P3> cloud((size_t)n);
+    for (int i = 0; i < n; ++i) std::memcpy(&cloud[(size_t)i], (const char*)xyz + (size_t)i * stride, 12);
+    float normals[3][4], mids[3][4];
+    int counts[3];
+    for (int i = 0; i < 3; ++i) {   // sne.cpp:183-197
+        cd_params q = *p;
+        q.plane_model = i == 0 ? CD_PLANE_PERPENDICULAR : CD_PLANE_PARALLEL;
+        for (int a = 0; a < 3; ++a) q.plane_axis[a] = table_normal[a];
+        q.plane_eps_angle = 0.1;                       // sne.cpp:123
+        q.plane_optimize = 1;                          // sne.cpp:118
+        q.plane_max_iterations = 1000;                 // sne.cpp:125
+        q.extract_negative = 1;
+        q.crop2_enable = 0;
+        q.bbox_enable = 0;
+        const int m = (int)cloud.size();
+        if (m > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+        st = load_as(c, cloud.data(), sizeof(P3), m, c->d_vox, &FrameState::n_v);
+        if (st) return st;
+        std::vector<int> iters;
+        st = stage_plane(c, 1, &q, iters, nullptr);
+        if (st) return st;
+        out->iterations[i] = iters[0];
+        if (!c->h_have[0]) return CD_ERR_NO_MODEL;
+        st = stage_extract(c, 1, &q);
+        if (st) return st;
+        st = sync_fs(c, 1);
+        if (st) return st;
+        const int ni = c->h_fs[0].n_plane;
+        std::vector<int> inl((size_t)std::max(ni, 1));
+        if (ni > 0) HIPCHK(c, copy_sync(c, inl.data(), c->d_plane_idx, sizeof(int) * ni, hipMemcpyDeviceToHost));
+        // getNormal(): plane_pc = ExtractIndices(negative = !invert), leftover = ExtractIndices(negative = invert)
+        std::vector<char> is_inl((size_t)std::max(m, 1), 0);
+        for (int k = 0; k < ni; ++k) is_inl[(size_t)inl[(size_t)k]] = 1;
+        std::vector<P3> plane_pc, leftover;
+        for (int k = 0; k < m; ++k) {
+            const bool in = is_inl[(size_t)k] != 0;
+            if (in == (invert != 0)) plane_pc.push_back(cloud[(size_t)k]); else leftover.push_back(cloud[(size_t)k]);
+        }
+        // pcl::compute3DCentroid: sequential float32 sums, then one division per component
+        float cs[3] = {0.f, 0.f, 0.f};
+        for (const P3& q3 : plane_pc) { cs[0] += q3.x; cs[1] += q3.y; cs[2] += q3.z; }
+        const float cnt = (float)plane_pc.size();
+        for (int a = 0; a < 3; ++a) mids[i][a] = cs[a] / cnt;
+        mids[i][3] = 0.f;
+        normals[i][0] = c->h_model[0].x; normals[i][1] = c->h_model[0].y; normals[i][2] = c->h_model[0].z; normals[i][3] = c->h_model[0].w;
+        counts[i] = (int)plane_pc.size();
+        cloud.swap(leftover);
+    }
+    // sne.cpp:199-212: order by size (the callback's own exchange loops), largest first
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j)
+            if (counts[i] < counts[j]) {
+                std::swap(counts[i], counts[j]);
+                for (int a = 0; a < 4; ++a) { std::swap(normals[i][a], normals[j][a]); std::swap(mids[i][a], mids[j][a]); }
+            }
+    hm::surface_frame(normals, mids, out->Rt);
+    for (int i = 0; i < 3; ++i) {
+        out->n_points[i] = counts[i];
+        for (int a = 0; a < 4; ++a) { out->coeff[i][a] = normals[i][a]; out->midpoint[i][a] = mids[i][a]; }
+    }
     return CD_OK;
 }
 

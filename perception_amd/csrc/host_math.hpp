@@ -123,6 +123,47 @@ inline void plane_refit_from_moments(const uint64_t S[10], const float model[4],
     out[3] = -1.0f * ((out[0] * a[6] + out[1] * a[7]) + out[2] * a[8]);
 }
 
+// isModelValid of pcl::SampleConsensusModelPerpendicularPlane / ...ParallelPlane (PCL 1.7.2), evaluated on the
+// host so that the CPU restatement and the GPU path share one libm (acos, sin).  type: CD_PLANE* of cuboid_hip.h.
+// Float 4-vector dot products / norms use the canonical association (x + y) + z (w = 0).
+inline bool plane_model_valid(int type, const float m[4], const float axis[3], double eps_angle) {
+    if (type == 0 || !(eps_angle > 0.0)) return true;
+    if (type == 1) {   // perpendicular plane: angle(axis, normal) folded into [0, pi/2] must be <= eps
+        const float dot = (axis[0] * m[0] + axis[1] * m[1]) + axis[2] * m[2];
+        const float n1 = (axis[0] * axis[0] + axis[1] * axis[1]) + axis[2] * axis[2];
+        const float n2 = (m[0] * m[0] + m[1] * m[1]) + m[2] * m[2];
+        double rad = dot / std::sqrt(n1 * n2);          // pcl::getAngle3D: float expression, clamped as double
+        if (rad < -1.0) rad = -1.0; else if (rad > 1.0) rad = 1.0;
+        double angle_diff = std::fabs(std::acos(rad));
+        angle_diff = std::min(angle_diff, M_PI - angle_diff);
+        return !(angle_diff > eps_angle);
+    }
+    // parallel plane: |axis . normalized(normal)| must be <= |sin(eps)|
+    const float nrm = std::sqrt((m[0] * m[0] + m[1] * m[1]) + m[2] * m[2]);
+    const float c[3] = {m[0] / nrm, m[1] / nrm, m[2] / nrm};
+    const float dot = (axis[0] * c[0] + axis[1] * c[1]) + axis[2] * c[2];
+    return !((double)std::fabs(dot) > std::fabs(std::sin(eps_angle)));
+}
+
+// surface_normal_estimation.cpp:207-222: make the frame right-handed, put the origin on plane 0's centroid moved
+// along normal 0 to the level of plane 1's centroid, assemble Rt = [n2 n1 n0 c].  normals/mids: sorted planes.
+// The third normal is flipped IN PLACE (the node publishes the flipped vector's plane as is; only Rt sees it).
+inline void surface_frame(const float normals[3][4], const float mids[3][4], float Rt[16]) {
+    const float* n0 = normals[0];
+    const float* n1 = normals[1];
+    float n2[3] = {normals[2][0], normals[2][1], normals[2][2]};
+    const float cr[3] = {n1[1] * n0[2] - n1[2] * n0[1], n1[2] * n0[0] - n1[0] * n0[2], n1[0] * n0[1] - n1[1] * n0[0]};   // n1 x n0
+    const float trip = (n2[0] * cr[0] + n2[1] * cr[1]) + n2[2] * cr[2];
+    if (trip < 0.f) { n2[0] = -n2[0]; n2[1] = -n2[1]; n2[2] = -n2[2]; }
+    const float d[3] = {mids[0][0] - mids[1][0], mids[0][1] - mids[1][1], mids[0][2] - mids[1][2]};
+    const float proj = (n0[0] * d[0] + n0[1] * d[1]) + n0[2] * d[2];
+    const float cen[3] = {mids[0][0] - proj * n0[0], mids[0][1] - proj * n0[1], mids[0][2] - proj * n0[2]};
+    for (int r = 0; r < 3; ++r) {
+        Rt[4 * r + 0] = n2[r]; Rt[4 * r + 1] = n1[r]; Rt[4 * r + 2] = n0[r]; Rt[4 * r + 3] = cen[r];
+    }
+    Rt[12] = 0.f; Rt[13] = 0.f; Rt[14] = 0.f; Rt[15] = 1.f;
+}
+
 // pcl::RandomSampleConsensus::computeModel's sequential bookkeeping, fed with the batched counts
 struct RansacReplay {
     int iterations = 0, skipped = 0, best = -INT32_MAX, best_h = -1, pos = 0;

@@ -241,6 +241,47 @@ def test_batch_cuboid_flavour_and_object_launch_params(ctx, O, template, frames4
         _same_cluster(rg.clusters[k], ro.clusters[k])
 
 
+def test_constrained_plane_models_and_surface_frame_bit_exact(ctx, O, template, frames4):
+    """Row 8f-3: SACMODEL_PERPENDICULAR_PLANE / PARALLEL_PLANE through cd_segment_plane and the whole
+    surface_normal_estimation callback through cd_surface_frame, against the oracle: inlier indices, coefficients,
+    iteration counts and the pose are bit-identical (the angular gate runs on the host in both, one libm)."""
+    from test_oracle_kat import _corner_cloud
+    from conftest import rot_xyz
+    rng = np.random.default_rng(21)
+    clouds = [_corner_cloud(rot_xyz(0.35, -0.2, 0.6), np.array([0.02, -0.03, 0.55]), rng),
+              _corner_cloud(rot_xyz(-0.5, 0.3, -1.1), np.array([-0.05, 0.04, 0.6]), rng, n_top=700, n_side_a=1600, n_side_b=900)]
+    axes = [rot_xyz(0.35, -0.2, 0.6)[:, 2], rot_xyz(-0.5, 0.3, -1.1)[:, 2]]
+    for pts, ax in zip(clouds, axes):
+        for model in (capi.CD_PLANE_PERPENDICULAR, capi.CD_PLANE_PARALLEL):
+            for axis in (ax, np.array([0.577, 0.577, 0.577])):
+                prm = capi.default_params()
+                prm.plane_distance_threshold = 0.002
+                prm.plane_model = model
+                prm.plane_eps_angle = 0.1
+                prm.plane_max_iterations = 200
+                for i in range(3):
+                    prm.plane_axis[i] = float(axis[i])
+                sg, cg, ig, itg = ctx.segment_plane(pts, prm)
+                so, co, io, ito = O.segment_plane(pts, prm)
+                assert sg == so and itg == ito, (model, axis)
+                assert [float(x).hex() for x in cg] == [float(x).hex() for x in co]
+                assert np.array_equal(ig, io)
+        prm = capi.default_params()
+        prm.plane_distance_threshold = 0.002
+        sg, rg = ctx.surface_frame(pts, ax.astype(np.float32), prm)
+        so, ro = O.surface_frame(pts, ax.astype(np.float32), prm)
+        assert sg == so == 0
+        assert bytes(rg) == bytes(ro)
+    # the real thing: the extracted object cloud of a synthetic frame and its table normal (gps -> sne in the reference)
+    prm = capi.default_params()
+    o = O.process_frame(frames4[1], prm, template, want_clouds=True)
+    normal = np.array(list(o["result"].plane)[:3], np.float32)
+    prm.plane_distance_threshold = 0.004
+    sg, rg = ctx.surface_frame(o["objects"], normal, prm)
+    so, ro = O.surface_frame(o["objects"], normal, prm)
+    assert sg == so and bytes(rg) == bytes(ro)
+
+
 def test_bbox_filter_stage_bit_exact(ctx, O, frames4):
     """cd_bbox_filter (stage level, what a bbox_filter node calls) against the oracle's within_bbox."""
     from perception_amd import synth

@@ -320,3 +320,67 @@ def test_bbox_filter_predicate(O):
     Pi = [100, 0, 0, 0, 0, 100, 0, 0, 0, 0, 1, 0]
     q = np.array([[1.0, 1.5, 1.0], [np.nextafter(np.float32(1.0), np.float32(2.0)), 1.5, 1.0], [2.0, 1.5, 1.0]], np.float32)
     assert list(O.bbox_filter(q, Pi, [100, 100, 200, 200])) == [1]
+
+
+def _corner_cloud(R, t, rng, n_top=1500, n_side_a=900, n_side_b=500, noise=0.0004):
+    """Three faces of a 0.2 x 0.1 x 0.06 box seen from a corner, in a frame rotated by R and moved by t."""
+    top = np.c_[rng.uniform(-0.1, 0.1, n_top), rng.uniform(-0.05, 0.05, n_top), np.full(n_top, 0.03)]
+    sa = np.c_[rng.uniform(-0.1, 0.1, n_side_a), np.full(n_side_a, -0.05), rng.uniform(-0.03, 0.03, n_side_a)]
+    sb = np.c_[np.full(n_side_b, -0.1), rng.uniform(-0.05, 0.05, n_side_b), rng.uniform(-0.03, 0.03, n_side_b)]
+    pts = np.concatenate([top, sa, sb]) + rng.normal(0, noise, (n_top + n_side_a + n_side_b, 3))
+    pts = pts[rng.permutation(len(pts))]
+    return (pts @ R.T + t).astype(np.float32)
+
+
+def test_axis_constrained_plane_models(O, prm):
+    """SACMODEL_PERPENDICULAR_PLANE / SACMODEL_PARALLEL_PLANE (surface_normal_estimation.cpp:118-123): the constraint
+    decides which face wins, not the inlier count alone."""
+    rng = np.random.default_rng(5)
+    R = rot_xyz(0.0, 0.0, 0.0)
+    pts = _corner_cloud(R, np.array([0, 0, 0.5]), rng, n_top=600, n_side_a=1500, n_side_b=400)
+    prm.plane_distance_threshold = 0.002
+    st, c0, inl0, _ = O.segment_plane(pts, prm)                      # unconstrained: the biggest face (side a, normal +-y)
+    assert st == 0 and abs(c0[1]) > 0.99 and 1450 < len(inl0) < 1650
+    prm.plane_model = capi.CD_PLANE_PERPENDICULAR
+    prm.plane_axis[0], prm.plane_axis[1], prm.plane_axis[2] = 0.0, 0.0, 1.0
+    prm.plane_eps_angle = 0.1
+    st, c1, inl1, _ = O.segment_plane(pts, prm)                      # normal parallel to z: the top face
+    assert st == 0 and abs(c1[2]) > 0.99 and 580 < len(inl1) < 720   # the face + the rims of the two side faces
+    prm.plane_model = capi.CD_PLANE_PARALLEL                         # normal perpendicular to z: side a again
+    st, c2, inl2, _ = O.segment_plane(pts, prm)
+    assert st == 0 and abs(c2[1]) > 0.99 and np.array_equal(inl2, inl0)
+    # an axis no face satisfies: the best hypothesis scores 0, PCL still reports its model, with no inliers
+    prm.plane_model = capi.CD_PLANE_PERPENDICULAR
+    prm.plane_axis[0], prm.plane_axis[1], prm.plane_axis[2] = 0.577, 0.577, 0.577
+    prm.plane_max_iterations = 50
+    st, c3, inl3, it3 = O.segment_plane(pts, prm)
+    assert st == 0 and len(inl3) == 0 and it3 == 51
+
+
+def test_surface_frame_known_answer(O, prm):
+    """surface_normal_estimation.cpp:167-234: the pose assembled from three constrained planes equals the box frame."""
+    rng = np.random.default_rng(9)
+    R = rot_xyz(0.35, -0.2, 0.6)
+    t = np.array([0.02, -0.03, 0.55])
+    pts = _corner_cloud(R, t, rng)
+    prm.plane_distance_threshold = 0.002
+    table_normal = (R @ np.array([0, 0, 1.0])).astype(np.float32)    # the table is parallel to the top face
+    st, res = O.surface_frame(pts, table_normal, prm, invert=True)
+    assert st == 0
+    n_pts = list(res.n_points)
+    assert n_pts == sorted(n_pts, reverse=True) and abs(n_pts[0] - 1500) < 60 and abs(n_pts[1] - 900) < 60 and abs(n_pts[2] - 500) < 60
+    Rt = np.array(list(res.Rt), np.float64).reshape(4, 4)
+    n0, n1, n2 = Rt[:3, 2], Rt[:3, 1], Rt[:3, 0]
+    # columns: +-z (top, largest), +-y (side a), +-x (side b) of the box, right-handed per sne.cpp:207-210
+    assert abs(abs(n0 @ R[:, 2]) - 1) < 1e-4 and abs(abs(n1 @ R[:, 1]) - 1) < 1e-4 and abs(abs(n2 @ R[:, 0]) - 1) < 1e-4
+    assert n2 @ np.cross(n1, n0) > 0.999
+    # origin: centroid of the top face moved along its normal to the height of side a's centroid (sne.cpp:213-214)
+    m0 = R @ np.array([0, 0, 0.03]) + t
+    m1 = R @ np.array([0, -0.05, 0.0]) + t
+    want = m0 - (n0 @ (m0 - m1)) * n0
+    assert np.linalg.norm(Rt[:3, 3] - want) < 2e-3
+    assert list(Rt[3]) == [0, 0, 0, 1]
+    # fewer than three planes: the third fit has nothing to find
+    flat = pts[np.abs((pts - t) @ R[:, 2] - 0.03) < 0.001]
+    st, _ = O.surface_frame(flat, table_normal, prm)
+    assert st == capi.CD_ERR_NO_MODEL
