@@ -45,3 +45,28 @@ def template_xyz32(length, width, height, density):
 
 # launch default: iterative_closest_point.launch:34,39-41
 DEFAULT_TEMPLATE = dict(length=0.2, width=0.1, height=0.03, density=0.002)
+
+
+def main(argv=None):
+    """`python -m perception_amd.templates -L 0.2 -W 0.1 -H 0.03 -d 0.002 [-f name]`: the command line of the
+    reference's make_cuboid.py (:4-21: flags, defaults, default file name, '.pcd' appended when missing)."""
+    import argparse
+    ap = argparse.ArgumentParser(description="write the 3-face cuboid template as an ASCII PCD v0.7 file")
+    ap.add_argument("-L", "--length", default=0.2, type=float, help="cuboid length (m)")
+    ap.add_argument("-W", "--width", default=0.1, type=float, help="cuboid width (m)")
+    ap.add_argument("-H", "--height", default=0.075, type=float, help="cuboid height (m)")
+    ap.add_argument("-d", "--density", default=0.002, type=float, help="sampling step (m)")
+    ap.add_argument("-f", "--filename", default="", type=str, help="output filename")
+    a = ap.parse_args(argv)
+    name = a.filename or template_filename(a.length, a.width, a.height)
+    if not name.endswith(".pcd"):
+        name += ".pcd"
+    data = template_pcd_bytes(a.length, a.width, a.height, a.density)
+    with open(name, "wb") as f:
+        f.write(data)
+    print('Saved "%s" with %d points' % (name, len(make_cuboid_template(a.length, a.width, a.height, a.density))))
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())
