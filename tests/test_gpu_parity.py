@@ -383,3 +383,75 @@ def test_icp_exact_ties_pick_lowest_original_index(ctx, O):
     assert st == s0 == 0
     _same_cluster(res, r0)
     assert np.array_equal(al.view(np.uint32), a0.view(np.uint32))
+
+
+def _random_scene(rng):
+    """A random table + boxes + clutter scene as an (n, 4) float32 cloud (x, y, z, rgb bits) with random holes/NaNs."""
+    n_plane = int(rng.integers(2000, 30000))
+    tilt = rot_xyz(*(rng.uniform(-0.6, 0.6, 3)))
+    z0 = rng.uniform(0.3, 0.8)
+    uv = rng.uniform(-0.35, 0.35, (n_plane, 2))
+    plane = np.c_[uv, np.zeros(n_plane)] @ tilt.T + [0, 0, z0]
+    parts = [plane + rng.normal(0, rng.uniform(0.0002, 0.002), plane.shape)]
+    for _ in range(int(rng.integers(0, 4))):
+        c = np.r_[rng.uniform(-0.15, 0.15, 2), 0.0] @ tilt.T + [0, 0, z0] - tilt[:, 2] * rng.uniform(0.01, 0.05)
+        ext = rng.uniform(0.02, 0.12, 3)
+        m = int(rng.integers(300, 5000))
+        box = rng.uniform(-1, 1, (m, 3)) * ext
+        face = rng.integers(0, 3, m)
+        box[np.arange(m), face] = ext[face] * rng.choice([-1, 1], m)
+        parts.append(box @ rot_xyz(*(rng.uniform(-1, 1, 3))).T + c)
+    parts.append(rng.uniform([-0.5, -0.5, -0.1], [0.5, 0.5, 1.2], (int(rng.integers(0, 800)), 3)))
+    pts = np.concatenate(parts).astype(np.float32)
+    pts = pts[rng.permutation(len(pts))]
+    bad = rng.random(len(pts)) < 0.01
+    pts[bad] = np.nan
+    out = np.zeros((len(pts), 4), np.float32)
+    out[:, :3] = pts
+    out[:, 3] = rng.integers(0, 1 << 24, len(pts)).astype(np.uint32).view(np.float32)
+    return out
+
+
+def test_randomised_scenes_and_parameters(O, template):
+    """40 random scenes x random launch parameters through the whole chain: every integer output identical, every
+    float output bit-identical to the oracle (plane, indices, labels, ICP transforms, fitness)."""
+    from conftest import rot_xyz as _r  # noqa: F401  (used by _random_scene through the module global)
+    rng = np.random.default_rng(20190409)
+    ctx2 = capi.Context(max_points=40000, max_frames=1)
+    try:
+        ctx2.set_template(0, template)
+        small = templates_small()
+        ctx2.set_template(1, small)
+        for case in range(40):
+            cloud = _random_scene(rng)
+            prm = capi.default_params()
+            prm.rgb_offset = 12 if case % 2 else -1
+            prm.leaf_size = float(rng.choice([0.004, 0.005, 0.0075, 0.01]))
+            prm.plane_distance_threshold = float(rng.choice([0.005, 0.01, 0.015]))
+            prm.plane_max_iterations = int(rng.choice([50, 1000]))
+            prm.crop_x_min, prm.crop_x_max = float(rng.uniform(-0.4, -0.1)), float(rng.uniform(0.1, 0.4))
+            prm.crop_z_max = float(rng.uniform(0.7, 1.0))
+            prm.crop2_enable = int(rng.integers(0, 2))
+            prm.cluster_enable = int(rng.integers(0, 2))
+            prm.cluster_tolerance = float(rng.choice([0.01, 0.02, 0.03]))
+            prm.cluster_min_size = int(rng.choice([20, 100, 200]))
+            prm.icp_max_iterations = int(rng.choice([5, 40, 5000]))
+            prm.template_slot = int(rng.integers(0, 2))
+            tpl = template if prm.template_slot == 0 else small
+            res, pi, lb = ctx2.process_batch(cloud[None], prm, want_indices=True)
+            o = O.process_frame(cloud, prm, tpl, want_clouds=True)
+            rg, ro = res[0], o["result"]
+            for k in ("status", "n_cropped", "n_voxels", "n_plane", "n_objects", "n_clusters", "ransac_iterations"):
+                assert getattr(rg, k) == getattr(ro, k), (case, k)
+            assert [float(x).hex() for x in rg.plane] == [float(x).hex() for x in ro.plane], case
+            assert np.array_equal(pi[0][:max(rg.n_plane, 0)], o["plane_inliers"]), case
+            assert np.array_equal(lb[0][:max(rg.n_objects, 0)], o["labels"]), case
+            for k in range(min(max(rg.n_clusters, 0), capi.CD_MAX_CLUSTERS_PER_FRAME)):
+                _same_cluster(rg.clusters[k], ro.clusters[k])
+    finally:
+        ctx2.close()
+
+
+def templates_small():
+    from perception_amd import templates as T
+    return T.template_xyz32(length=0.2, width=0.075, height=0.1, density=0.005)
