@@ -15,6 +15,8 @@
  *   gps.cpp = cuboid_detection/src/ground_plane_segmentation.cpp
  *   icp.cpp = cuboid_detection/src/iterative_closest_point.cpp
  *   opd.cpp = object_detection/src/object_pose_detection.cpp
+ *   sne.cpp = cuboid_detection/src/surface_normal_estimation.cpp (constrained planes, surface frame)
+ *   cuboid_detection/src/bbox_filter.cpp (image-space gate)
  * It is pinned by what the tree does hold (tests/test_oracle_*.py): make_cuboid.py output
  * bytes, the *_ascii.pcd <-> *_ascii_tf.pcd <-> transforms.txt rigid-transform fixtures,
  * std::mt19937 known answers, and analytic known-answer cases.
@@ -29,6 +31,8 @@
  *      2^-36 for squared distances) and summed in 64-bit integers.
  *   C5 nearest neighbour ties -> lowest template index; cluster labels = rank by
  *      (size descending, first member index ascending).
+ *   C6 3-vector dots / norms of the constrained plane models and the surface frame: (x + y) + z;
+ *      compute3DCentroid: sequential float32 sums in point order.
  */
 #include <algorithm>
 #include <array>
