@@ -207,7 +207,10 @@ int cd_process_batch(cd_context* ctx, const void* frames, size_t stride_bytes,
                      int points_per_frame, int n_frames, const cd_params* prm,
                      cd_frame_result* results, int32_t* plane_inliers, int32_t* labels);
 
-/* Same, input already resident in device memory (HBM) of the context's GPU. */
+/* Same, input already resident in device memory (HBM) of the context's GPU.  A context works on its own
+ * non-blocking HIP stream: there is no implicit ordering against the NULL stream or any other stream, so the
+ * caller must have completed its writes to d_frames (e.g. hipStreamSynchronize on the producing stream)
+ * before the call.  The call itself is synchronous: results are final when it returns. */
 int cd_process_batch_device(cd_context* ctx, const void* d_frames, size_t stride_bytes,
                             int points_per_frame, int n_frames, const cd_params* prm,
                             cd_frame_result* results, int32_t* plane_inliers,
