@@ -258,7 +258,7 @@ def main():
             "icp": {"clusters": ncl, "accepted": int(acc), "mean_iterations": float(np.mean(iters)) if iters else 0.0,
                     "max_iterations": int(max(iters)) if iters else 0, "frames": nfr},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames, prm, tpl)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
