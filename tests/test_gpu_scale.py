@@ -1,5 +1,7 @@
 """GPU tests at BASELINE.json's larger sizes, through size-independent properties plus one
 oracle comparison at 1 M points (config 5's frame size)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -165,3 +167,36 @@ def test_batches_in_flight_give_the_same_records(template):
             assert np.array_equal(rec, w)
     finally:
         pipe.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["sliced", "cluster", "pipe"])
+def test_irregular_templates_in_every_driver(O, mode, monkeypatch):
+    """Real D435 clusters from the reference tree (irregular density, holes) as TEMPLATES: the uniform grid is sized
+    from their median point spacing, cells hold anything from 0 to dozens of points, the seed balls reach outside the
+    grid - the lane-per-query walk and the run-box search must still return the oracle's bits in every driver."""
+    from conftest import GOLDEN, rot_xyz
+    from perception_amd import pcd
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    rng = np.random.default_rng(77)
+    ctx = capi.Context(max_points=8192, max_frames=1)
+    try:
+        for slot, name in enumerate(("marker_ascii.pcd", "screwdriver_ascii.pcd", "eraser_ascii.pcd")):
+            tpl = pcd.read_xyz(os.path.join(GOLDEN, name)).astype(np.float32)
+            ctx.set_template(slot, tpl)
+            for trial in range(4):
+                keep = rng.random(len(tpl)) < rng.uniform(0.4, 1.0)
+                R = rot_xyz(*(rng.uniform(-0.08, 0.08, 3)))
+                c = tpl.mean(0)
+                src = ((tpl[keep] - c) @ R.T + c + rng.uniform(-0.01, 0.01, 3) + rng.normal(0, 0.0005, (keep.sum(), 3))).astype(np.float32)
+                if trial == 3:
+                    src = src + np.float32(0.25)          # far outside the template's grid: every seed ball is huge at first
+                prm = capi.default_params()
+                prm.icp_max_iterations = 60
+                st, res, _ = ctx.icp(slot, src, prm)
+                s0, r0, _ = O.icp(tpl, src, prm, nn_mode=1)
+                assert st == s0 == 0
+                assert (res.iterations, res.converged) == (r0.iterations, r0.converged), (mode, name, trial)
+                assert list(res.T) == list(r0.T) and res.fitness == r0.fitness, (mode, name, trial)
+    finally:
+        ctx.close()
