@@ -1,7 +1,7 @@
 """Single-frame latency breakdown (BASELINE config 2)."""
 import sys, time
 import numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from perception_amd import capi, synth, templates
 tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)

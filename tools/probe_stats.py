@@ -1,5 +1,5 @@
 import sys, ctypes as C, numpy as np
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from perception_amd import capi, synth, templates
 lib = capi.load_library()
 tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
