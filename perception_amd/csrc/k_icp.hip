@@ -894,7 +894,7 @@ struct PipeSlot {
     int phase, it;
     int arrived;                    // waves that finished their share of the current step
     int epoch;                      // steps completed (solved) so far
-    int pad;
+    int next_pass;                  // next 64-point pass of the current step nobody has taken yet
 };
 
 // Umeyama + convergence test of one iteration (lane 0 of the finishing wave); same code as k_icp_solve.
@@ -966,7 +966,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             PipeSlot* sl = &s_slot[sidx];
             for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
-            sl->arrived = 0; sl->epoch = 0; sl->phase = PH_FILL; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0;
+            sl->arrived = 0; sl->epoch = 0; sl->phase = PH_FILL; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
         }
         // slot 0 starts with a cluster; slot 1 is filled by its first finisher, after every workgroup took its first
         pipe_refill(&s_slot[0], ncl, order, cl, st, queue);
@@ -995,10 +995,19 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                 float4* pts = src + sl->src_off;
                 const float4* pts0 = src0 + sl->src_off;
                 int* nnq = nn + sl->src_off;
-                for (int q0 = 0; q0 < n; q0 += ICPT_THREADS) {
-                    const int nq = min(ICPT_THREADS, n - q0);
-                    const int myq = q0 + wave + ICPT_WAVES * lane;
-                    const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                // The step's queries are cut into passes of 64 consecutive points; waves PULL passes from the slot's
+                // counter, so a wave that drew cheap passes (certainly-near queries) simply takes more of them and all
+                // waves reach the end of the step together.  (A point is then touched by different waves in different
+                // steps: same CU, and the step boundary is a workgroup-scope release/acquire.)
+                const int npass = (n + 63) >> 6;
+                for (;;) {
+                    int pss = 0;
+                    if (lane == 0) pss = atomicAdd(&sl->next_pass, 1);
+                    pss = __builtin_amdgcn_readfirstlane(pss);
+                    if (pss >= npass) break;
+                    const int q0 = pss << 6;
+                    const int nk = min(64, n - q0);
+                    const int myq = q0 + lane;
                     QueryRegs q;
                     q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
                     if (lane < nk) {
@@ -1094,6 +1103,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     }
                     for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
                     sl->arrived = 0;
+                    sl->next_pass = 0;
                 }
                 __threadfence_block();
                 if (lane == 0) __hip_atomic_store(&sl->epoch, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
