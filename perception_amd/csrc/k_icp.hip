@@ -706,11 +706,11 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
             for (int i = 0; i < 16; ++i) S[i] = 0ull;
             for (int q0 = 0; q0 < c.n; q0 += ICPT_THREADS) {
                 const int nq = min(ICPT_THREADS, c.n - q0);
-                const int myq = q0 + wave + ICPT_WAVES * lane;
-                QueryRegs q;
+                const int myq = q0 + wave * WAVE + lane;   // a wave takes 64 consecutive points: coalesced, and neighbours in
+                QueryRegs q;                               // voxel order have neighbouring answers (less divergence per pass)
                 int nk;
                 // fetch (+ X <- T*X written back by the lane that owns the point)
-                nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                nk = min(WAVE, max(0, nq - wave * WAVE));
                 q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
                 if (lane < nk) {
                     const float4 p = pts[myq];
@@ -815,8 +815,8 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
             for (int i = 0; i < 16; ++i) S[i] = 0ull;
             for (int q0 = 0; q0 < c.n; q0 += ICPT_THREADS) {
                 const int nq = min(ICPT_THREADS, c.n - q0);
-                const int myq = q0 + wave + ICPT_WAVES * lane;
-                const int nk = nq > wave ? (nq - wave + ICPT_WAVES - 1) / ICPT_WAVES : 0;
+                const int myq = q0 + wave * WAVE + lane;
+                const int nk = min(WAVE, max(0, nq - wave * WAVE));
                 QueryRegs q;
                 q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
                 if (lane < nk) {
