@@ -83,8 +83,8 @@ def cpu_baseline(frames, prm, tpl, budget_s=20.0, max_frames=96):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 3: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="also measure single-frame latency (BASELINE config 2) after the timed region")
