@@ -48,6 +48,7 @@ struct cd_context {
     float4 *d_tpl = nullptr, *d_tlo = nullptr, *d_thi = nullptr;   // points + per-64-run boxes
     float4 *d_tplk = nullptr, *d_tlok = nullptr, *d_thik = nullptr;   // templates in k-d patch order (sliced path)
     IcpGrid* d_grid = nullptr;                                    // per template slot
+    unsigned short* d_kdmap = nullptr;                            // k-d patch order -> cell-sorted position (resident templates)
     unsigned short* d_tcell = nullptr;                            // cell start tables, ICP_CELL_STRIDE entries per slot
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
     float* d_d2 = nullptr;                                        // its squared distance
@@ -344,7 +345,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
         if (pipe_ok)
-            launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+            launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                             c->d_queue, c->n_cu, ip);
         else
             launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
@@ -640,7 +641,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
@@ -685,6 +686,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_grid, (size_t)CD_MAX_TEMPLATES) == hipSuccess && dalloc(&c->d_tcell, (size_t)CD_MAX_TEMPLATES * ICP_CELL_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
+    ok = ok && dalloc(&c->d_kdmap, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tplk, (size_t)c->tpl_cap) == hipSuccess && dalloc(&c->d_tlok, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thik, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)4) == hipSuccess;
     {
@@ -829,6 +831,8 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         return CD_OK;
     };
     if (int ust = upload(c->d_tpl, c->d_tlo, c->d_thi)) return ust;   // layout 1: cell-sorted (whole-cluster kernels)
+    std::vector<int> pos_cell((size_t)m);                             // original index -> position in layout 1
+    for (int i = 0; i < m; ++i) pos_cell[(size_t)tp[(size_t)i].oi] = i;
     {
         // Layout 2, for the sliced multi-launch path (few clusters spread over many CUs, wave-per-query search
         // only): compact patches of 64 points from k-d median splits whose left part is a multiple of 64, so
@@ -861,6 +865,13 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         }
     }
     if (int ust = upload(c->d_tplk, c->d_tlok, c->d_thik)) return ust;
+    if (m <= ICP_TPL_LDS) {
+        // k-d patch r = the cell-sorted positions kdmap[64 r .. 64 r + 63]: the pipelined kernel searches far queries
+        // patch by patch THROUGH this table (compact boxes) while the points themselves stay cell-sorted in LDS
+        std::vector<unsigned short> kdmap((size_t)m_pad, (unsigned short)m_pad);   // padding -> the +inf pad run
+        for (int i = 0; i < m; ++i) kdmap[(size_t)i] = (unsigned short)pos_cell[(size_t)tp[(size_t)i].oi];
+        HIPCHK(c, copy_sync(c, c->d_kdmap + off, kdmap.data(), sizeof(unsigned short) * kdmap.size(), hipMemcpyHostToDevice));
+    }
     if (!cell_start.empty())
         HIPCHK(c, copy_sync(c, c->d_tcell + grid.cell_off, cell_start.data(), sizeof(unsigned short) * cell_start.size(), hipMemcpyHostToDevice));
     HIPCHK(c, copy_sync(c, c->d_grid + slot, &grid, sizeof(grid), hipMemcpyHostToDevice));

@@ -465,6 +465,85 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
     }
 }
 
+// search_chunk over k-d PATCHES of a cell-sorted template: run r = the 64 stored positions s_kd[64 r ..], its box in bx.
+// The points stay where the grid walk wants them; the wave-per-query search gets the compact boxes it wants.
+__device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
+                                               unsigned long long todo) {
+    const int c0 = 0;
+    const int lane = threadIdx.x & 63;
+#ifdef CD_STATS
+    const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
+#endif
+    while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+        const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+        // Lanes start from (bound, no index): a lane can only be selected below if it beat `best`, and the
+        // seed point itself always does in the chunk that holds it.  Only when `best` is a real distance
+        // carried over from a lower chunk (c0 > 0) must ties against the carried neighbour be decided,
+        // so only then is its original index needed.
+        const int boi = c0 > 0 ? __builtin_amdgcn_readlane(q.poi, k) : 0x7fffffff;
+        unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
+        unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
+#ifdef CD_STATS
+        if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+        float lbest = best;
+        int lbi = 0, loi = boi;
+        // Visit the surviving runs (1.5 per query on average, so no unrolling/padding).  The template is stored
+        // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
+        // order: the update is the lexicographic (d2, original index) comparison (rule C5).
+#define CD_TAKE(dd, tt, rr)                                                                     \
+        {                                                                                       \
+            const int oi_ = __float_as_int(tt.w);                                               \
+            const bool up_ = (dd < lbest) || (dd == lbest && oi_ < loi);                        \
+            lbest = up_ ? dd : lbest; lbi = up_ ? p0_ : lbi; loi = up_ ? oi_ : loi; \
+        }
+#define CD_VISIT2(mask, base)                                                                   \
+        while (mask) {                                                                          \
+            const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;             \
+            const int p0_ = s_kd[r0 * ICP_SUB + lane];                                          \
+            const float4 t0 = s_tpl[p0_];                                                       \
+            const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                                  \
+            CD_TAKE(d0, t0, r0)                                                                 \
+        }
+        CD_VISIT2(m0, 0)
+        CD_VISIT2(m1, 64)
+#undef CD_VISIT2
+#undef CD_TAKE
+        // lexicographic (d2, original index) minimum over the wave.  Only lanes that beat the incoming
+        // bound can hold it; when exactly one did (the usual case once seeds are tight) it IS the answer
+        // and three v_readlane replace the reduction.  Otherwise: min distance by DPP, then the lowest
+        // original index among the lanes that hold it.
+        const unsigned long long imp = __ballot(lbest < best || (lbest == best && loi < boi));
+        if (imp == 0) continue;   // nothing in this chunk beats the carried neighbour (multi-chunk templates only)
+        float dmin;
+        int rbi, roi;
+        if (__popcll(imp) == 1) {
+            const int l = __ffsll((long long)imp) - 1;
+            dmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), l));
+            rbi = __builtin_amdgcn_readlane(lbi, l);
+            roi = __builtin_amdgcn_readlane(loi, l);
+        } else {
+            dmin = wave_min_f32_nonneg(lbest);
+            unsigned long long eq = __ballot(lbest == dmin);
+            rbi = 0; roi = 0x7fffffff;
+            while (eq) {
+                const int l = __ffsll((long long)eq) - 1;
+                eq &= eq - 1;
+                const int oi_ = __builtin_amdgcn_readlane(loi, l);
+                const int bi_ = __builtin_amdgcn_readlane(lbi, l);
+                if (oi_ <= roi) { roi = oi_; rbi = bi_; }
+            }
+        }
+        if (lane == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
+    }
+}
+
+
 __device__ __forceinline__ void store_queries(const QueryRegs& q, int nk, int* nn, float* d2buf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < nk) {
@@ -946,12 +1025,15 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                                                            const IcpCluster* __restrict__ cl, IcpState* st,
                                                            unsigned long long* __restrict__ accf,
                                                            const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                           const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
+                                                           const float4* __restrict__ thi,
+                                                           const unsigned short* __restrict__ kdmap,
+                                                           const IcpGrid* __restrict__ grids,
                                                            const unsigned short* __restrict__ tcell, float4* src,
                                                            const float4* __restrict__ src0, int* nn, int* queue, IcpParams prm) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
+    __shared__ unsigned short s_kd[ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // every cluster of one launch uses the same (LDS-resident, gridded) template - the host guarantees it
     const IcpCluster c0 = cl[order[0]];
@@ -961,6 +1043,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     const float rmax = __fmul_rn(prm.grid_rc, g.cell);
     RunBoxes bx;
     for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
+    for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = kdmap[c0.tpl_off + i];
     stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
     if (threadIdx.x == 0) {
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
@@ -1049,7 +1132,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
                     if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
-                    search_chunk(s_tpl, bx, 0, tpl_m, q, __ballot(lane < nk && !near));
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near));
                     if (lane < nk) {
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
@@ -1193,13 +1276,13 @@ void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpClust
 }
 
 void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
-                     const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
+                     const float4* tpl, const float4* tlo, const float4* thi, const unsigned short* kdmap, const IcpGrid* grids,
                      const unsigned short* tcell, float4* src, const float4* src0, int* nn,
                      int* queue, int n_cu, IcpParams prm) {
     if (ncl <= 0) return;
     hipMemsetAsync(queue, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_icp_pipe, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
-                       grids, tcell, src, src0, nn, queue, prm);
+                       kdmap, grids, tcell, src, src0, nn, queue, prm);
 }
 
 }  // namespace cd
