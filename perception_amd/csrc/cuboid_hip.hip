@@ -326,7 +326,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
     IcpParams ip;
     ip.max_iter = p->icp_max_iterations;
-    ip.grid_rc = 1.5f;
+    ip.grid_rc = 1.0f;
     if (const char* e = std::getenv("CUBOID_ICP_GRID_RC")) ip.grid_rc = (float)std::atof(e);
     ip.trans_eps = p->icp_transformation_epsilon;
     ip.rel_mse = p->icp_euclidean_fitness_epsilon;
