@@ -1132,6 +1132,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
                     if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+#ifdef CD_STATS
+                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+#endif
                     search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near));
                     if (lane < nk) {
                         if (phase == PH_ITER) {

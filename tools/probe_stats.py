@@ -1,3 +1,4 @@
+"""Counters / phase timers of the ICP kernels (needs a -DCD_STATS or -DCD_TIMERS build of perception_amd/csrc)."""
 import sys, ctypes as C, numpy as np
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from perception_amd import capi, synth, templates
@@ -14,10 +15,10 @@ res, _, _ = ctx.process_batch(fr, prm)
 lib.cd_debug_icp_stats(out, 1)
 o = list(out)
 q = max(o[0], 1)
-print('queries', o[0], 'certified %.3f  grid+collect %.3f  grid plain %.3f  wave-per-query %.3f (runs visited %.2f)' % (o[3] / q, o[8] / q, o[9] / q, o[2] / q, o[1] / max(o[2], 1)))
-scans = max((o[8] + o[9]) / 64, 1)
-print('grid per 64-lane pass (if all lanes scanned): row-step iterations %.1f (active %.1f) point iterations %.1f (active %.1f)' % (o[4] / scans, o[5] / max(o[4], 1), o[6] / scans, o[7] / max(o[6], 1)))
-print('grid per scanned query: row steps %.2f points %.2f' % (o[5] / max(o[8] + o[9], 1), o[7] / max(o[8] + o[9], 1)))
+passes = max(q / 64.0, 1)
+print('CD_STATS: queries %d  near (grid walk) %.3f  far (wave-per-query) %.3f, runs visited per far query %.2f' % (o[0], o[3] / q, o[2] / q, o[1] / max(o[2], 1)))
+print('CD_STATS: grid walk per 64-query pass: row-step iterations %.1f (active lanes %.1f), point iterations %.1f (active lanes %.1f)' % (o[4] / passes, o[5] / max(o[4], 1), o[6] / passes, o[7] / max(o[6], 1)))
+print('CD_STATS: per near query: row steps %.2f, points tested %.2f' % (o[5] / max(o[3], 1), o[7] / max(o[3], 1)))
 ph = o[8:14]
 tot = max(sum(ph), 1)
-print('timers (CD_TIMERS builds only): ' + ' '.join('%.1f%%' % (100.0 * x / tot) for x in ph), 'total %.3g' % tot)
+print('CD_TIMERS: wave cycles by phase ' + ' '.join('%.1f%%' % (100.0 * x / tot) for x in ph), 'total %.3g' % tot)
