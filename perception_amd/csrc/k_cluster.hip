@@ -217,7 +217,9 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __rest
                     cell_of(q, org, inv_cell, jx, jy, jz);
                     take = jx == cx + a && jy == cy + b && jz == cz + c;
                 }
-                if (take && dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2) {
+                // a neighbour that already hangs directly under i's root needs no find and no union (most pairs of a big
+                // cluster once the first unions and path halvings have happened): one LDS read instead of a chain walk
+                if (take && dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2 && s_par[j] != ri) {
                     int rj = lds_find(s_par, j);
                     while (ri != rj) {
                         const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
