@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 3: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--latency", action="store_true", help="also measure single-frame latency (BASELINE config 2) after the timed region")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial)")
     args = ap.parse_args()
