@@ -200,3 +200,29 @@ def test_irregular_templates_in_every_driver(O, mode, monkeypatch):
                 assert list(res.T) == list(r0.T) and res.fitness == r0.fitness, (mode, name, trial)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["cluster", "pipe"])
+def test_whole_cluster_drivers_on_odd_sizes(O, template, mode, monkeypatch):
+    """Pass boundaries of the whole-cluster kernels: sources of 3, 63, 64, 65, 127, 129, 1025 and 20 000 points (passes are
+    64 consecutive points pulled by waves; the last one is ragged) must give the oracle's bits."""
+    from conftest import rot_xyz
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    rng = np.random.default_rng(3)
+    ctx = capi.Context(max_points=32768, max_frames=1)
+    try:
+        ctx.set_template(0, template)
+        for n in (3, 63, 64, 65, 127, 129, 1025, 20000):
+            idx = rng.integers(0, len(template), n)
+            R = rot_xyz(*(rng.uniform(-0.05, 0.05, 3)))
+            src = (template[idx] @ R.T + rng.uniform(-0.004, 0.004, 3) + rng.normal(0, 0.0007, (n, 3))).astype(np.float32)
+            prm = capi.default_params()
+            prm.icp_max_iterations = 40
+            st, res, _ = ctx.icp(0, src, prm)
+            s0, r0, _ = O.icp(template, src, prm, nn_mode=1)
+            assert st == s0, (mode, n)
+            assert (res.iterations, res.converged) == (r0.iterations, r0.converged), (mode, n)
+            assert list(res.T) == list(r0.T) and res.fitness == r0.fitness, (mode, n)
+    finally:
+        ctx.close()
