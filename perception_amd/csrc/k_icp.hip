@@ -1057,6 +1057,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     __syncthreads();
 #ifdef CD_TIMERS
     long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+    const long long wg_t0 = wall_clock64();
 #endif
     int my_epoch0 = 0, my_epoch1 = 0;
     bool live0 = true, live1 = true;
@@ -1200,6 +1201,10 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     }
 #ifdef CD_TIMERS
     if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_icp_stats[8 + i], (unsigned long long)tph[i]);
+    if (threadIdx.x == 0) {   // workgroup busy time (100 MHz wall clock): sum, max, count
+        const unsigned long long dt = (unsigned long long)(wall_clock64() - wg_t0);
+        atomicAdd(&g_icp_stats[14], dt); atomicMax(&g_icp_stats[15], dt); atomicAdd(&g_icp_stats[7], 1ull);
+    }
 #endif
 }
 

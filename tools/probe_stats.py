@@ -22,3 +22,5 @@ print('CD_STATS: per near query: row steps %.2f, points tested %.2f' % (o[5] / m
 ph = o[8:14]
 tot = max(sum(ph), 1)
 print('CD_TIMERS: wave cycles by phase ' + ' '.join('%.1f%%' % (100.0 * x / tot) for x in ph), 'total %.3g' % tot)
+if o[15]:
+    print('CD_TIMERS: workgroup busy time mean %.3f ms, max %.3f ms over %d workgroups (balance %.2f)' % (o[14] / max(o[7], 1) / 1e5, o[15] / 1e5, o[7], o[14] / max(o[7], 1) / max(o[15], 1)))
