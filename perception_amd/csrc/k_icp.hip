@@ -378,12 +378,18 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
             { const unsigned long long pb_ = __ballot(more && i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
 #endif
             if (more && i < b) {
+                // two points per trip (the second one is the first again when the range ends: a no-op for the update)
+                const int i1 = i + 1 < b ? i + 1 : i;
                 const float4 t = s_tpl[i];
+                const float4 u = s_tpl[i1];
                 const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
-                const int o = __float_as_int(t.w);
+                const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
+                const int o = __float_as_int(t.w), o1 = __float_as_int(u.w);
                 const bool up = (d < lbest) || (d == lbest && o < loi);
                 lbest = up ? d : lbest; lbi = up ? i : lbi; loi = up ? o : loi;
-                ++i;
+                const bool up1 = (e < lbest) || (e == lbest && o1 < loi);
+                lbest = up1 ? e : lbest; lbi = up1 ? i1 : lbi; loi = up1 ? o1 : loi;
+                i += 2;
             }
         }
     }
