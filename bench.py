@@ -29,6 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak
+PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # HBM bytes per dispatch from the separate --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def _render(i):
@@ -52,20 +53,46 @@ def make_frames(start, count):
     return out
 
 
-def cpu_baseline(frames, prm, tpl, budget_s=20.0, max_frames=96):
+def _same_as_oracle(rg, ro):
+    """counts, plane bits, and per cluster size / iterations / flags / T bits / fitness of a GPU record vs the oracle's"""
+    if (rg.status, rg.n_cropped, rg.n_voxels, rg.n_plane, rg.n_objects, rg.n_clusters, rg.ransac_iterations) != \
+       (ro.status, ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters, ro.ransac_iterations):
+        return False
+    if bytes(rg.plane) != bytes(ro.plane):
+        return False
+    for k in range(min(ro.n_clusters, len(ro.clusters))):
+        a, b = rg.clusters[k], ro.clusters[k]
+        if (a.size, a.iterations, a.converged, a.accepted, bytes(a.T), a.fitness) != (b.size, b.iterations, b.converged, b.accepted, bytes(b.T), b.fitness):
+            return False
+        if float(np.linalg.norm(np.array(a.pose) - np.array(b.pose))) >= 1e-4:
+            return False
+    return True
+
+
+def cpu_baseline(frames, prm, tpl, budget_s=20.0, max_frames=96, gpu_records=None):
     """The CPU oracle (kind 'port': a restatement of the PCL chain, kd-tree NN, grid clustering)
-    timed on one host thread over a bounded sample of the same frames."""
+    timed on one host thread over a bounded sample of the same frames.  The oracle is the CHECKER here as well: the
+    records it produces for the sampled frames are compared with the GPU records of the last timed step."""
     from oracle import oracle_py as O      # allowed: bench.py's cpu_baseline leg
+    from perception_amd import capi
     O.lib()
     O.process_frame(frames[0], prm, tpl, nn_mode=1)   # warm
-    n, t0 = 0, time.perf_counter()
+    gpu = capi.results_from_array(gpu_records) if gpu_records is not None else None
+    n, t0, bad = 0, time.perf_counter(), []
+    orec = []
     while n < min(max_frames, len(frames)) and (time.perf_counter() - t0) < budget_s:
-        O.process_frame(frames[n], prm, tpl, nn_mode=1)
+        orec.append(O.process_frame(frames[n], prm, tpl, nn_mode=1)["result"])
         n += 1
     dt = time.perf_counter() - t0
+    if gpu is not None:
+        bad = [i for i in range(n) if not _same_as_oracle(gpu[i], orec[i])]
     out = {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "first %d frames of the bench batch, oracle/liboracle.so (g++ -O2), 1 thread, %.1f s" % (n, dt),
            "host_cpus": os.cpu_count()}
+    if gpu is not None:
+        out["oracle_check"] = {"frames": n, "ok": not bad, "mismatching_frames": bad[:8],
+                               "what": "GPU records of the last timed step vs the oracle: counts, plane bits, per-cluster size/"
+                                       "iterations/converged/accepted/T bits/fitness identical, pose Frobenius < 1e-4"}
     # SURVEY 8(d) also asks for the frame-parallel figure: one frame per thread (ctypes releases the GIL), on the
     # box's CPU share for one GPU
     from concurrent.futures import ThreadPoolExecutor
@@ -80,23 +107,114 @@ def cpu_baseline(frames, prm, tpl, budget_s=20.0, max_frames=96):
     return out
 
 
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` without a launcher: start N fresh rank processes (one per GPU) and relay rank 0's JSON line.
+    Runs BEFORE this process imports torch or touches HIP - a process that has initialised the GPU must never be
+    re-executed or forked - and the parent only waits.  Children get RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* exactly as
+    torch.distributed.run would set them."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    procs = []
+    with tempfile.TemporaryFile() as out0:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL))
+        # wait for all; if one rank fails the others would sit in a collective until its timeout: end them (these exact
+        # children, by handle)
+        code = 0
+        live = list(procs)
+        while live:
+            time.sleep(0.2)
+            for p in list(live):
+                rc = p.poll()
+                if rc is None:
+                    continue
+                live.remove(p)
+                if rc != 0 and code == 0:
+                    code = abs(rc) or 1
+                    for q in live:
+                        q.terminate()
+        out0.seek(0)
+        sys.stdout.write(out0.read().decode())
+        sys.stdout.flush()
+    return code
+
+
+class stdout_to_stderr:
+    """RCCL (and gloo) print a banner (host name, library path, peer count) on stdout when a communicator comes up; stdout
+    is reserved for the one JSON line, so file descriptor 1 points at stderr while the process group initialises."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+        return False
+
+
+def dry_run(rank, local_rank, world):
+    import torch
+    import torch.distributed as dist
+    ids = [(rank, local_rank)]
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        with stdout_to_stderr():
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = [torch.zeros(2, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(t, torch.tensor([rank, local_rank], dtype=torch.int64))
+            ids = [tuple(int(v) for v in x) for x in t]
+            dist.barrier()
+            dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "ranks": [i[0] for i in ids], "local_ranks": [i[1] for i in ids]}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to use, one rank process per GPU (default: WORLD_SIZE or 1)")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300, about 2.5 s of timed region)")
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 3: 256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--latency", action="store_true", help="also measure single-frame latency (BASELINE config 2) after the timed region")
+    ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency measurement (BASELINE config 2; runs after the timed region)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed path's records (runs after the timed region)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, gather their rank ids and rank 0 "
+                         "prints them (tests/test_bench_launcher.py)")
     ap.add_argument("--inflight", type=int, default=3,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial)")
     args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 300
+    if args.steps < 1 or args.warmup < 0 or args.frames < 1:
+        raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 
+    env_world = int(os.environ["WORLD_SIZE"]) if "WORLD_SIZE" in os.environ else None
+    if env_world is None and (args.gpus or 1) > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))          # parent: no torch, no HIP
+    if env_world is not None and args.gpus is not None and args.gpus != env_world:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, env_world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = env_world or 1
     F = args.frames
+    if args.dry_run:
+        return dry_run(rank, local_rank, world)
 
     # host-side inputs first (fork pool must not follow GPU init)
     frames = make_frames(rank * F, F)
@@ -107,25 +225,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d but this node shows %d" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or os.environ.get("CUBOID_BENCH_FORCE_DIST") == "1"   # force: rehearse the RCCL path with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        # RCCL prints a banner (host name, library path) on stdout when its communicator comes up; stdout is reserved
-        # for the one JSON line, so file descriptor 1 points at stderr until the first collective has run
-        sys.stdout.flush()
-        saved_fd = os.dup(1)
-        os.dup2(2, 1)
-        try:
+        with stdout_to_stderr():          # until the first collective has run
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
-        finally:
-            sys.stdout.flush()
-            os.dup2(saved_fd, 1)
-            os.close(saved_fd)
 
     tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
     prm = capi.default_params()
@@ -195,12 +306,30 @@ def main():
     balg, icp_balg = t.algorithmic_bytes, t.icp_algorithmic_bytes
     one = (capi.CdFrameResult * 1)()
     lat = [float("nan")]
-    for _ in range(5 if args.latency else 0):
+    for _ in range(0 if args.no_latency else 12):
         torch.cuda.synchronize()
         a = time.perf_counter()
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, 1, prm, results=one)
         lat.append((time.perf_counter() - a) * 1e3)
 
+    # Self-check of the timed path, outside the timed region: the records of the LAST timed step (k_icp_pipe with refilled
+    # slots, other batches in flight, gathered over all ranks) must be byte-identical to a strictly serial pass of this
+    # rank's batch on an otherwise idle GPU.
+    verified = None
+    serial_rec = None
+    if not args.no_verify:
+        fence()
+        res = (capi.CdFrameResult * F)()
+        ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
+        serial_rec = capi.results_to_array(res).copy()
+        ok = bool(np.array_equal(serial_rec, allrec[rank * F:(rank + 1) * F]))
+        if use_dist:
+            tv = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(tv, op=dist.ReduceOp.MIN)
+            ok = bool(tv.item())
+        verified = ok
+
+    exit_code = 0
     if rank == 0:
         recs = capi.results_from_array(allrec)
         nfr = len(recs)
@@ -220,7 +349,7 @@ def main():
         whole = icp_launches == args.steps
         icp_kernel = ("k_icp_cluster" if os.environ.get("CUBOID_ICP_MODE") == "cluster" else "k_icp_pipe") if whole else "k_icp_iter"
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
             if F == 256 and N == 307200:
                 traffic = pmc["kernels"][icp_kernel]["hbm_bytes_per_dispatch"]
         except (OSError, KeyError, ValueError):
@@ -230,8 +359,12 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "batch of %d synthetic 640x480 D435 frames per GPU (BASELINE config 3), cuboid launch "
-                                   "parameters, 7250-point template, full chain S0-S6 + pose-record gather" % F,
+            "config": {"workload": ("batch of %d synthetic 640x480 D435 frames per GPU (BASELINE config 3), cuboid launch "
+                                    "parameters, 7250-point template, full chain S0-S6 + pose-record gather" % F) if world == 1 else
+                                   ("batch of %d synthetic 640x480 D435 frames sharded frame-per-GPU over %d GPUs, %d per GPU "
+                                    "(BASELINE config 4%s), RCCL all_gather of the pose records per batch; per GPU the config-3 "
+                                    "workload" % (F * world, world, F, "" if F * world == 2048 else " shape")),
+                       "rccl_ranks": (dist.get_world_size() if use_dist else 0),
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "batches_in_flight": M,
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
@@ -254,19 +387,29 @@ def main():
             "stage_ms_per_step": {"crop_voxel": stage[0] / args.steps, "plane": stage[1] / args.steps,
                                   "extract_cluster": stage[2] / args.steps, "icp": stage[3] / args.steps,
                                   "device_total": stage[4] / args.steps},
-            "single_frame_ms": ({"median": float(np.median(lat[1:])), "min": float(np.min(lat[1:]))} if args.latency else None),
+            "single_frame_ms": ({"median": float(np.median(lat[2:])), "min": float(np.min(lat[2:])),
+                                 "note": "BASELINE config 2: one frame, full chain, device-resident input, host wall clock of the "
+                                         "synchronous C-ABI call; measured after the timed region"} if len(lat) > 2 else None),
+            "verified": verified,
+            "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "
+                             "byte-identical to a strictly serial pass run after the timed region",
             "icp": {"clusters": ncl, "accepted": int(acc), "mean_iterations": float(np.mean(iters)) if iters else 0.0,
                     "max_iterations": int(max(iters)) if iters else 0, "frames": nfr},
         }
         if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(frames, prm, tpl)
+            out["cpu_baseline"] = cpu_baseline(frames, prm, tpl, gpu_records=allrec)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))
+        if verified is False or out.get("cpu_baseline", {}).get("oracle_check", {}).get("ok") is False:
+            sys.stdout.flush()
+            print("bench.py: the timed path's records FAILED verification", file=sys.stderr)
+            exit_code = 1
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     pipe.close()
+    return exit_code
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -55,6 +55,7 @@ struct cd_context {
     int* d_queue = nullptr;                                       // ICP work queue head
     int n_cu = 256;
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
+    int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
@@ -344,12 +345,13 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
+        const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
         if (pipe_ok)
             launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                            c->d_queue, c->n_cu, ip);
+                            c->d_queue, wg_cap, ip);
         else
             launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                               c->d_queue, c->n_cu, ip);
+                               c->d_queue, wg_cap, ip);
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         c->timing.icp_kernel_launches = 1;
         HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
@@ -697,6 +699,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
+    if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;

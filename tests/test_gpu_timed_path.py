@@ -1,0 +1,107 @@
+"""Parity of the path bench.py TIMES, at the size it times it.
+
+BASELINE config 3 = 256 synthetic frames per GPU through perception_amd.batch.BatchPipeline with three batches in
+flight; the ICP stage auto-selects k_icp_pipe, whose grid is min(clusters, CUs) persistent workgroups: with ~520
+clusters on 256 workgroups every workgroup refills its two slots from the queue (pipe_refill into a used slot, the
+PH_FIT -> refill hand-over, two live slots per workgroup).  Every record of every batch is compared with the CPU
+oracle (reference chain: object_detection/src/object_pose_detection.cpp:270-413, one ICP per cluster :376-413).
+The cheap variant caps the ICP grid at 2 workgroups (CUBOID_ICP_MAX_WG) so that the refill paths run in every CI run."""
+import os
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+from perception_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-4   # BASELINE.json north_star
+
+
+def _oracle_records(O, frames, prm, tpl, threads=16):
+    """oracle records of `frames`, frame-parallel on host threads (ctypes releases the GIL)."""
+    O.lib()
+    with ThreadPoolExecutor(max(1, min(threads, os.cpu_count() or 1))) as ex:
+        return list(ex.map(lambda f: O.process_frame(f, prm, tpl, nn_mode=1)["result"], frames))
+
+
+def assert_record_matches_oracle(rg, ro, tag):
+    assert (rg.status, rg.n_cropped, rg.n_voxels, rg.n_plane, rg.n_objects, rg.n_clusters, rg.ransac_iterations) == \
+           (ro.status, ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters, ro.ransac_iterations), tag
+    assert np.array_equal(np.array(rg.plane, np.float32).view(np.uint32), np.array(ro.plane, np.float32).view(np.uint32)), tag
+    for k in range(min(ro.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+        a, b = rg.clusters[k], ro.clusters[k]
+        assert (a.size, a.iterations, a.converged, a.accepted) == (b.size, b.iterations, b.converged, b.accepted), (tag, k)
+        assert list(a.T) == list(b.T), (tag, k, "final transformation not bit-identical")
+        assert a.fitness == b.fitness, (tag, k)
+        assert np.linalg.norm(np.array(a.pose) - np.array(b.pose)) < POSE_TOL, (tag, k)
+
+
+def _render(lo, n):
+    with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+        return np.stack(list(ex.map(synth.frame, range(lo, lo + n))), 0)
+
+
+def test_bench_config3_three_batches_in_flight_vs_oracle(O, template):
+    """Exactly what bench.py times: 256 frames per batch, default ICP mode (auto -> k_icp_pipe), BatchPipeline(inflight=3),
+    four consecutive batches (so every context is reused while the others are busy); every record vs the oracle."""
+    import torch
+    from perception_amd import batch
+    F = 256
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    sets = [_render(0, F), _render(F, F)]
+    want = [_oracle_records(O, s, prm, template) for s in sets]
+    ncl = sum(min(r.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME) for r in want[0])
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    assert ncl >= 2 * n_cu - 8, "the batch must hold ~2 clusters per CU so that k_icp_pipe refills its slots (got %d on %d CUs)" % (ncl, n_cu)
+    dev = [torch.from_numpy(s).cuda() for s in sets]
+    torch.cuda.synchronize()
+    N = sets[0].shape[1]
+    pipe = batch.BatchPipeline(N, F, {0: template}, inflight=3)
+    try:
+        order = [0, 1, 0, 1, 1, 0]
+        futs = [pipe.submit(dev[i].data_ptr(), 16, N, F, prm) for i in order]
+        for step, (i, fut) in enumerate(zip(order, futs)):
+            rec, tim = fut.result()
+            assert tim.icp_kernel_launches == 1, "batch mode must run ONE persistent ICP launch (k_icp_pipe)"
+            got = capi.results_from_array(rec)
+            for f in range(F):
+                assert_record_matches_oracle(got[f], want[i][f], ("step", step, "frame", i * F + f))
+    finally:
+        pipe.close()
+
+
+@pytest.mark.parametrize("max_wg", ["1", "2", "5"])
+def test_pipe_slot_refill_with_capped_grid(O, template, max_wg, monkeypatch):
+    """k_icp_pipe on 1, 2 or 5 workgroups with ~20 clusters: every slot is refilled several times, the two slots of a
+    workgroup hold clusters at different iterations, and the last clusters leave one slot exhausted while the other
+    still works.  Records must equal the oracle's, and the sliced driver's bytes."""
+    idx = list(range(40, 50))
+    frames = np.stack([synth.frame(i) for i in idx], 0)
+    prm = capi.default_params()
+    want = _oracle_records(O, frames, prm, template)
+    assert sum(r.n_clusters for r in want) >= 12
+    monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    monkeypatch.setenv("CUBOID_ICP_MAX_WG", max_wg)
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, template)
+        for rep in range(2):                      # the second call reuses the queue / state buffers
+            res, _, _ = ctx.process_batch(frames, prm)
+            assert ctx.timing().icp_kernel_launches == 1
+            for f in range(len(frames)):
+                assert_record_matches_oracle(res[f], want[f], (max_wg, rep, idx[f]))
+        pipe_bytes = capi.results_to_array(res).copy()
+    finally:
+        ctx.close()
+    monkeypatch.setenv("CUBOID_ICP_MODE", "sliced")
+    monkeypatch.delenv("CUBOID_ICP_MAX_WG")
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, template)
+        res, _, _ = ctx.process_batch(frames, prm)
+        assert np.array_equal(capi.results_to_array(res), pipe_bytes)
+    finally:
+        ctx.close()
