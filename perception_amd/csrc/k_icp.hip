@@ -201,6 +201,16 @@ extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef CD_ITSTATS
+__device__ unsigned long long g_icp_it[32][4];   // per ICP iteration (31 = fitness pass): pass cycles, passes, far queries, patches visited
+extern "C" int cd_debug_icp_it(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_it), sizeof(g_icp_it)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[32][4]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_it), z, sizeof(z)); }
+    return 0;
+}
+__device__ int g_icp_cur_it;   // iteration bucket of the pass a wave is in (approximate: last writer wins; only read by the stats)
+#endif
+
 #ifdef CD_TIMERS
 #define CD_PHASE(n) { const long long tn_ = clock64(); tph[n] += tn_ - tlast; tlast = tn_; }
 #else
@@ -474,7 +484,7 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
 // search_chunk over k-d PATCHES of a cell-sorted template: run r = the 64 stored positions s_kd[64 r ..], its box in bx.
 // The points stay where the grid walk wants them; the wave-per-query search gets the compact boxes it wants.
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
-                                               unsigned long long todo) {
+                                               unsigned long long todo, int* stat_acc = nullptr) {
     const int c0 = 0;
     const int lane = threadIdx.x & 63;
 #ifdef CD_STATS
@@ -496,6 +506,9 @@ __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsign
         unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
 #ifdef CD_STATS
         if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+#ifdef CD_ITSTATS
+        if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += __popcll(m0) + __popcll(m1); }
 #endif
         float lbest = best;
         int lbi = 0, loi = boi;
@@ -1098,6 +1111,10 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     const int q0 = pss << 6;
                     const int nk = min(64, n - q0);
                     const int myq = q0 + lane;
+#ifdef CD_ITSTATS
+                    const long long tpass0 = clock64();
+                    const int stat_it = phase == PH_ITER ? min(it, 30) : 31;
+#endif
                     QueryRegs q;
                     q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
                     if (lane < nk) {
@@ -1142,7 +1159,16 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
 #ifdef CD_STATS
                     { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
+#ifdef CD_ITSTATS
+                    int stat_acc[2] = {0, 0};
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), stat_acc);
+                    if (lane == 0) {
+                        atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
+                        atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
+                    }
+#else
                     search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near));
+#endif
                     if (lane < nk) {
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
