@@ -37,9 +37,11 @@
 extern "C" {
 #endif
 
-#define CD_ABI_VERSION 1
+#define CD_ABI_VERSION 2
 #define CD_MAX_TEMPLATES 8          /* template slots per context (BASELINE config 5 uses 5) */
-#define CD_MAX_CLUSTERS_PER_FRAME 8 /* cluster slots in the fixed-size per-frame record      */
+#define CD_MAX_CLUSTERS_PER_FRAME 8 /* cluster slots in the fixed-size per-frame record; a frame with more clusters still
+                                     * gets an ICP for every one of them (opd.cpp:376): see cd_get_cluster_results       */
+#define CD_FRAME_MORE_CLUSTERS 1    /* cd_frame_result.flags: n_clusters > CD_MAX_CLUSTERS_PER_FRAME                    */
 
 typedef struct cd_context cd_context;
 
@@ -137,7 +139,7 @@ typedef struct cd_frame_result {
     int32_t n_objects;     /* N_o points after S3(+S3b)                               */
     int32_t n_clusters;    /* K clusters found (may exceed the slots below)           */
     int32_t ransac_iterations; /* PCL iterations_ consumed by the adaptive loop       */
-    int32_t reserved;
+    int32_t flags;         /* CD_FRAME_MORE_CLUSTERS                                  */
     float plane[4];        /* refined coefficients a,b,c,d                            */
     float pad[4];
     cd_cluster_result clusters[CD_MAX_CLUSTERS_PER_FRAME]; /* size-descending          */
@@ -206,6 +208,14 @@ int cd_icp(cd_context* ctx, int slot, const void* src_xyz, size_t stride_bytes, 
 int cd_process_batch(cd_context* ctx, const void* frames, size_t stride_bytes,
                      int points_per_frame, int n_frames, const cd_params* prm,
                      cd_frame_result* results, int32_t* plane_inliers, int32_t* labels);
+
+/* opd.cpp:376-413 runs ICP on EVERY cluster of the frame and picks among all of them (:416-423).  The fixed-size record
+ * carries the CD_MAX_CLUSTERS_PER_FRAME largest; when a frame has more (flags & CD_FRAME_MORE_CLUSTERS) the others - all of
+ * them were registered as well - are read here.  Copies the results of clusters [first, first + capacity) of `frame`
+ * (rank order: size descending) of the LAST cd_process_batch* call of this context into `out`; *out_total (may be NULL)
+ * receives the number of clusters of that frame.  Returns the number of results copied, or a negative cd_status. */
+int cd_get_cluster_results(const cd_context* ctx, int frame, int first, int capacity, cd_cluster_result* out,
+                           int* out_total);
 
 /* Same, input already resident in device memory (HBM) of the context's GPU.  A context works on its own
  * non-blocking HIP stream: there is no implicit ordering against the NULL stream or any other stream, so the

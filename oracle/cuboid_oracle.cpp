@@ -1285,10 +1285,14 @@ void orc_bbox_corners(const double H[16], double l, double w, double h, float ou
 
 // Whole chain for one frame: the stage order of opd.cpp:270-413 with the cuboid launch
 // parameters.  plane_inliers / labels may be NULL; capacities are n.
-int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* prm, const void* tgt,
-                      size_t tstride, int m, int nn_mode, cd_frame_result* res, int32_t* plane_inliers,
-                      int32_t* labels, float* voxel_xyz /* n*3 or NULL */, float* object_xyz /* n*3 or NULL */) {
+// all_clusters (may be NULL): the ICP result of EVERY cluster (opd.cpp:376-413 loops over all of object_cluster_indices;
+// the fixed-size record only has room for the CD_MAX_CLUSTERS_PER_FRAME largest), capacity all_cap, count in *n_all.
+int orc_process_frame_all(const void* pts, size_t stride, int n, const cd_params* prm, const void* tgt,
+                          size_t tstride, int m, int nn_mode, cd_frame_result* res, int32_t* plane_inliers,
+                          int32_t* labels, float* voxel_xyz /* n*3 or NULL */, float* object_xyz /* n*3 or NULL */,
+                          cd_cluster_result* all_clusters, int all_cap, int* n_all) {
     std::memset(res, 0, sizeof(*res));
+    if (n_all) *n_all = 0;
     Cloud c{(const uint8_t*)pts, stride, n};
     std::vector<int> a, b;
     passthrough(c, nullptr, 2, prm->crop_z_min, prm->crop_z_max, a);
@@ -1347,8 +1351,10 @@ int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* pr
         sz.push_back(no);
     }
     res->n_clusters = (int)sz.size();
+    res->flags = (int)sz.size() > CD_MAX_CLUSTERS_PER_FRAME ? CD_FRAME_MORE_CLUSTERS : 0;
     if (labels) std::memcpy(labels, lab.data(), (size_t)no * 4);
-    for (int k = 0; k < (int)sz.size() && k < CD_MAX_CLUSTERS_PER_FRAME; ++k) {
+    const int k_icp = all_clusters ? std::min((int)sz.size(), std::max(all_cap, CD_MAX_CLUSTERS_PER_FRAME)) : std::min((int)sz.size(), CD_MAX_CLUSTERS_PER_FRAME);
+    for (int k = 0; k < k_icp; ++k) {
         std::vector<float> src;
         src.reserve((size_t)sz[k] * 3);
         for (int i = 0; i < no; ++i)
@@ -1358,9 +1364,19 @@ int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* pr
         IcpOut io;
         icp_align(src.data(), sz[k], T.data(), m, nn_mode, prm->icp_max_iterations,
                   prm->icp_transformation_epsilon, prm->icp_euclidean_fitness_epsilon, io);
-        fill_cluster_result(io, sz[k], prm->icp_accept_fitness, &res->clusters[k]);
+        cd_cluster_result cr;
+        fill_cluster_result(io, sz[k], prm->icp_accept_fitness, &cr);
+        if (k < CD_MAX_CLUSTERS_PER_FRAME) res->clusters[k] = cr;
+        if (all_clusters && k < all_cap) { all_clusters[k] = cr; if (n_all) *n_all = k + 1; }
     }
     return CD_OK;
+}
+
+int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* prm, const void* tgt,
+                      size_t tstride, int m, int nn_mode, cd_frame_result* res, int32_t* plane_inliers,
+                      int32_t* labels, float* voxel_xyz, float* object_xyz) {
+    return orc_process_frame_all(pts, stride, n, prm, tgt, tstride, m, nn_mode, res, plane_inliers, labels, voxel_xyz, object_xyz,
+                                 nullptr, 0, nullptr);
 }
 
 }  // extern "C"

@@ -179,8 +179,9 @@ def bbox_corners(H, l, w, h):
     return out
 
 
-def process_frame(points, prm, template, nn_mode=1, want_clouds=False):
-    """One frame through the whole chain.  Returns dict(result, plane_inliers, labels[, voxels, objects])."""
+def process_frame(points, prm, template, nn_mode=1, want_clouds=False, all_clusters=0):
+    """One frame through the whole chain.  Returns dict(result, plane_inliers, labels[, voxels, objects][, clusters]).
+    all_clusters = capacity of the list of per-cluster ICP results beyond the record's fixed slots (0: record only)."""
     a, st, n = _pts(points)
     t, ts, m = _pts(template)
     res = CdFrameResult()
@@ -188,10 +189,14 @@ def process_frame(points, prm, template, nn_mode=1, want_clouds=False):
     lb = np.empty(max(n, 1), np.int32)
     vox = np.empty((max(n, 1), 3), np.float32) if want_clouds else None
     obj = np.empty((max(n, 1), 3), np.float32) if want_clouds else None
-    s = lib().orc_process_frame(_p(a), st, n, C.byref(prm), _p(t), ts, m, nn_mode, C.byref(res), _p(pi), _p(lb),
-                                _p(vox), _p(obj))
+    allc = (CdClusterResult * max(all_clusters, 1))()
+    nall = C.c_int()
+    s = lib().orc_process_frame_all(_p(a), st, n, C.byref(prm), _p(t), ts, m, nn_mode, C.byref(res), _p(pi), _p(lb),
+                                    _p(vox), _p(obj), allc if all_clusters else None, all_clusters, C.byref(nall))
     out = dict(status=s, result=res, plane_inliers=pi[:max(res.n_plane, 0)].copy(),
                labels=lb[:max(res.n_objects, 0)].copy())
+    if all_clusters:
+        out["clusters"] = [allc[i] for i in range(nall.value)]
     if want_clouds:
         out["voxels"] = vox[:res.n_voxels].copy()
         out["objects"] = obj[:res.n_objects].copy()

@@ -9,8 +9,10 @@ import os
 
 import numpy as np
 
+CD_ABI_VERSION = 2
 CD_MAX_TEMPLATES = 8
 CD_MAX_CLUSTERS_PER_FRAME = 8
+CD_FRAME_MORE_CLUSTERS = 1
 
 CD_OK = 0
 CD_ERR_INVALID_ARG = -1
@@ -27,7 +29,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libc
 EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
     "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
-    "cd_process_batch", "cd_process_batch_device", "cd_pose_to_position_quaternion",
+    "cd_process_batch", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing",
 ]
 
@@ -75,7 +77,7 @@ class CdFrameResult(C.Structure):
     _fields_ = [
         ("status", C.c_int32), ("n_cropped", C.c_int32), ("n_voxels", C.c_int32),
         ("n_plane", C.c_int32), ("n_objects", C.c_int32), ("n_clusters", C.c_int32),
-        ("ransac_iterations", C.c_int32), ("reserved", C.c_int32),
+        ("ransac_iterations", C.c_int32), ("flags", C.c_int32),
         ("plane", C.c_float * 4), ("pad", C.c_float * 4),
         ("clusters", CdClusterResult * CD_MAX_CLUSTERS_PER_FRAME),
     ]
@@ -158,6 +160,7 @@ def load_library(path=None):
                            C.POINTER(CdClusterResult), vp]
     for f in (lib.cd_process_batch, lib.cd_process_batch_device):
         f.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(CdParams), vp, vp, vp]
+    lib.cd_get_cluster_results.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CdClusterResult), ip]
     lib.cd_pose_to_position_quaternion.argtypes = [C.POINTER(C.c_double)] * 3
     lib.cd_pose_to_position_quaternion.restype = None
     lib.cd_bbox_corners.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, f32p]
@@ -290,6 +293,17 @@ class Context:
                                                      C.cast(res, C.c_void_p), _ptr(plane_inliers),
                                                      _ptr(labels)))
         return res
+
+    def cluster_results(self, frame, first=0, count=None):
+        """ICP results of EVERY cluster of `frame` of the last process_batch* call (opd.cpp:376 registers all of them; the
+        fixed-size record holds the CD_MAX_CLUSTERS_PER_FRAME largest)."""
+        tot = C.c_int()
+        self._check(min(0, self.lib.cd_get_cluster_results(self.h, frame, 0, 0, None, C.byref(tot))))
+        n = max(0, tot.value - first) if count is None else count
+        out = (CdClusterResult * max(n, 1))()
+        got = self.lib.cd_get_cluster_results(self.h, frame, first, n, out, None)
+        self._check(min(0, got))
+        return [out[i] for i in range(got)]
 
     def timing(self):
         t = CdTiming()

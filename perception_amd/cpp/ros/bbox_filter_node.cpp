@@ -62,6 +62,7 @@ int main(int argc, char** argv) {
     ros::Subscriber pcl_sub = nh.subscribe("/ground_plane_segmentation/points", 1, pcl_cb);
     pcl_pub = nh.advertise<sensor_msgs::PointCloud2>("/bbox_filter/points", 1);
     ros::spin();
+    return 0;
 }
 #else
 int main() { return 0; }

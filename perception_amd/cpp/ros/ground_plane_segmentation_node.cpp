@@ -23,7 +23,12 @@ static int field_offset(const sensor_msgs::PointCloud2& m, const char* name) {
 }
 
 void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
-    // The PointCloud2 blob goes to the device as it is: x,y,z float32 at offsets 0/4/8, stride = point_step.
+    // The PointCloud2 blob goes to the device as it is: x,y,z float32 at offsets 0/4/8 (what every PCL point type and the
+    // D435 driver use), stride = point_step.
+    if (field_offset(*input, "x") != 0 || field_offset(*input, "y") != 4 || field_offset(*input, "z") != 8) {
+        ROS_ERROR("ground_plane_segmentation: expected float32 x,y,z at byte offsets 0,4,8 of a record");
+        return;
+    }
     cd_context* ctx = pclhip::Device::instance((int)(input->width * input->height)).ctx();
     cd_params prm;
     cd_default_params(&prm);
@@ -47,27 +52,36 @@ void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
     ros_coefficients.header = input->header;
     if (st == CD_OK) ros_coefficients.values.assign(coeff, coeff + 4);
     coef_pub.publish(ros_coefficients);
-    // ExtractIndices(negative=invert): x,y,z,rgb records of the kept voxel centroids
+    // ExtractIndices<PCLPointCloud2>(negative = invert) + fromPCL (gps.cpp:96-112): the published cloud carries the INPUT's
+    // field table and point_step - VoxelGrid<PCLPointCloud2> and ExtractIndices<PCLPointCloud2> both copy them - with one
+    // record per kept voxel: centroid at the x,y,z offsets, averaged colour at the rgb offset, padding bytes zero.
+    // (PCL also averages any OTHER field as a float32; the D435 driver publishes none, and here they stay zero.)
     std::vector<char> is_inl((size_t)std::max(nv, 1), 0);
     for (int k = 0; k < ni; ++k) is_inl[(size_t)inl[(size_t)k]] = 1;
+    const int ox = field_offset(*input, "x"), oy = field_offset(*input, "y"), oz = field_offset(*input, "z");
+    const int orgb = prm.rgb_offset >= 0 ? prm.rgb_offset : field_offset(*input, "rgba");
     sensor_msgs::PointCloud2 out;
     out.header = input->header;
     out.height = 1;
     out.is_dense = true;
-    out.is_bigendian = false;
-    out.fields.resize(4);
-    const char* names[4] = {"x", "y", "z", "rgb"};
-    for (int k = 0; k < 4; ++k) { out.fields[k].name = names[k]; out.fields[k].offset = 4 * k; out.fields[k].datatype = sensor_msgs::PointField::FLOAT32; out.fields[k].count = 1; }
-    out.point_step = 16;
+    out.is_bigendian = input->is_bigendian;
+    out.fields = input->fields;
+    out.point_step = input->point_step;
+    size_t kept = 0;
+    for (int i = 0; i < nv; ++i) kept += ((is_inl[(size_t)i] != 0) == invert) ? 0 : 1;
+    out.data.assign(kept * out.point_step, 0);
+    size_t o = 0;
     for (int i = 0; i < nv; ++i) {
         if ((is_inl[(size_t)i] != 0) == invert) continue;
-        const size_t o = out.data.size();
-        out.data.resize(o + 16);
-        std::memcpy(&out.data[o], &vox[3 * (size_t)i], 12);
-        std::memcpy(&out.data[o + 12], &rgb[(size_t)i], 4);
+        uint8_t* rec = &out.data[o];
+        std::memcpy(rec + ox, &vox[3 * (size_t)i], 4);
+        std::memcpy(rec + oy, &vox[3 * (size_t)i + 1], 4);
+        std::memcpy(rec + oz, &vox[3 * (size_t)i + 2], 4);
+        if (orgb >= 0 && (size_t)orgb + 4 <= out.point_step) std::memcpy(rec + orgb, &rgb[(size_t)i], 4);
+        o += out.point_step;
     }
-    out.width = (uint32_t)(out.data.size() / 16);
-    out.row_step = out.width * 16;
+    out.width = (uint32_t)kept;
+    out.row_step = out.width * out.point_step;
     pcl_pub.publish(out);
 }
 
@@ -84,6 +98,7 @@ int main(int argc, char** argv) {
     pcl_pub = nh.advertise<sensor_msgs::PointCloud2>(output_topic, 1);
     coef_pub = nh.advertise<pcl_msgs::ModelCoefficients>(coefficients_topic, 1);
     ros::spin();
+    return 0;
 }
 #else
 int main() { return 0; }   // ROS is not available in this build environment

@@ -84,6 +84,7 @@ int main(int argc, char** argv) {
     template_pub = nh.advertise<sensor_msgs::PointCloud2>("/icp/template", 1);
     pose_pub = nh.advertise<geometry_msgs::Pose>("/icp/pose", 1);
     ros::spin();
+    return 0;
 }
 #else
 int main() { return 0; }

@@ -67,14 +67,19 @@ bool service_callback(object_detection::ObjectDetection::Request& req, object_de
     prm.icp_accept_fitness = icp_fitness_score;
     cd_frame_result r;
     if (cd_process_batch(ctx, input_pcl->data.data(), input_pcl->point_step, n, 1, &prm, &r, nullptr, nullptr) != CD_OK) { ROS_ERROR("%s", cd_last_error(ctx)); return false; }
+    // opd.cpp:376-423: EVERY cluster was registered and the pick is over all of them; the record holds the
+    // CD_MAX_CLUSTERS_PER_FRAME largest, a frame with more (CD_FRAME_MORE_CLUSTERS) hands out the rest on request
+    std::vector<cd_cluster_result> all((size_t)std::max(r.n_clusters, 1));
+    const int got = cd_get_cluster_results(ctx, 0, 0, r.n_clusters, all.data(), nullptr);
+    if (got != r.n_clusters) { ROS_ERROR("cd_get_cluster_results: %d of %d clusters", got, r.n_clusters); return false; }
     long min_score = 1000;                                 // opd.cpp:416-423
     int argmin = -1;
-    for (int k = 0; k < std::min(r.n_clusters, (int32_t)CD_MAX_CLUSTERS_PER_FRAME); ++k) {
-        const long diff = std::labs((long)r.clusters[k].size - (long)loaded_template_size[id]);
+    for (int k = 0; k < got; ++k) {
+        const long diff = std::labs((long)all[(size_t)k].size - (long)loaded_template_size[id]);
         if (diff < min_score) { argmin = k; min_score = diff; }
     }
     if (argmin < 0) { ICP_SUCCESS = false; return false; } // the reference indexes icp_transforms[-1] here (undefined)
-    chosen = r.clusters[argmin];
+    chosen = all[(size_t)argmin];
     ICP_SUCCESS = min_score < 250;                         // opd.cpp:429
     res.success = ICP_SUCCESS;
     return ICP_SUCCESS;
@@ -95,6 +100,7 @@ int main(int argc, char** argv) {
     ros::ServiceServer service = nh.advertiseService("detect_objects", service_callback);
     pose_pub = nh.advertise<geometry_msgs::Pose>("/icp/pose", 1);
     ros::spin();
+    return 0;
 }
 #else
 int main() { return 0; }

@@ -73,6 +73,7 @@ int main(int argc, char** argv) {
     normal_z_pub = nh.advertise<pcl_msgs::ModelCoefficients>("/surface_segmentation/normal_z_coefficients", 1);
     pose_pub = nh.advertise<geometry_msgs::Pose>("/surface_segmentation/pose", 1);
     ros::spin();
+    return 0;
 }
 #else
 int main() { return 0; }

@@ -64,6 +64,11 @@ struct cd_context {
     IcpCluster *d_cl = nullptr, *h_cl = nullptr;
     IcpWork *d_work = nullptr, *h_work = nullptr, *d_work2 = nullptr, *h_work2 = nullptr;
     int work_cap = 0;
+    int cl_cap = 0;                                               // ICP problems the cluster arrays hold (grown on demand)
+    int* d_koffx = nullptr;                                       // offsets of the clusters ranked >= KICP, [round][F][KICP]
+    size_t koffx_cap = 0;
+    std::vector<cd_cluster_result> last_clusters;                 // every cluster result of the last batch, frame-major
+    std::vector<int> last_first;                                  // index of frame f's first cluster in it (F + 1 entries)
     IcpState *d_st = nullptr, *h_st = nullptr;
     unsigned long long *d_acc = nullptr, *d_accf = nullptr, *h_accf = nullptr;
     hipEvent_t ev[8] = {nullptr};
@@ -102,6 +107,33 @@ int ensure_input(cd_context* c, size_t bytes) {
     c->d_in_bytes = 0;
     HIPCHK(c, hipMalloc((void**)&c->d_in, bytes));
     c->d_in_bytes = bytes;
+    return CD_OK;
+}
+
+// cluster-indexed ICP arrays: sized for F * KICP problems at cd_create, re-allocated when a batch holds more
+// (frames with more than KICP clusters) - no cluster is dropped
+int ensure_clusters(cd_context* c, int ncl, long long points) {
+    const long long work_need = points / 64 + (long long)ncl + 16;
+    if (ncl <= c->cl_cap && work_need <= c->work_cap) return CD_OK;
+    if (work_need > 0x7fffffffll) return fail(c, CD_ERR_CAPACITY, "ICP work list exceeds 2^31 items");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    void* dev[] = {c->d_cl, c->d_order, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+    for (void* p : dev) if (p) hipFree(p);
+    void* host[] = {c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
+    for (void* p : host) if (p) hipHostFree(p);
+    c->d_cl = nullptr; c->d_order = nullptr; c->d_work = nullptr; c->d_work2 = nullptr; c->d_st = nullptr; c->d_acc = nullptr; c->d_accf = nullptr;
+    c->h_cl = nullptr; c->h_order = nullptr; c->h_work = nullptr; c->h_work2 = nullptr; c->h_st = nullptr; c->h_accf = nullptr;
+    // never shrink: the per-stage entry points (cd_icp) rely on the capacity cd_create gave them
+    const size_t n = (size_t)std::max(std::max(ncl, c->F * KICP) + ncl / 4, c->cl_cap), w = (size_t)std::max<long long>(work_need + work_need / 4, c->work_cap);
+    c->cl_cap = 0; c->work_cap = 0;
+    HIPCHK(c, dalloc(&c->d_cl, n)); HIPCHK(c, halloc(&c->h_cl, n));
+    HIPCHK(c, dalloc(&c->d_order, n)); HIPCHK(c, halloc(&c->h_order, n));
+    HIPCHK(c, dalloc(&c->d_work, w)); HIPCHK(c, halloc(&c->h_work, w));
+    HIPCHK(c, dalloc(&c->d_work2, w)); HIPCHK(c, halloc(&c->h_work2, w));
+    HIPCHK(c, dalloc(&c->d_st, n * 2)); HIPCHK(c, halloc(&c->h_st, n * 2));
+    HIPCHK(c, dalloc(&c->d_acc, n * 48)); HIPCHK(c, dalloc(&c->d_accf, n)); HIPCHK(c, halloc(&c->h_accf, n));
+    c->cl_cap = (int)n;
+    c->work_cap = (int)w;
     return CD_OK;
 }
 
@@ -287,9 +319,9 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint) {
     }
     launch_cluster_rank(c->stream, c->N, F, c->d_fs, p->cluster_enable, p->cluster_min_size, p->cluster_max_size, c->d_parent, c->d_csize, c->d_cand, c->d_rank, c->d_sizes);
     HIPCHK(c, hipMemsetAsync(c->d_tileK, 0, sizeof(int) * (size_t)F * KICP * T, c->stream));
-    launch_label_count(c->stream, c->N, F, T, To, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK);
+    launch_label_count(c->stream, c->N, F, T, To, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK, 0);
     launch_scan_tiles(c->stream, c->d_tileK, F * KICP, T, nullptr, 0);
-    launch_label_scatter(c->stream, c->d_obj, c->N, F, T, To, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src);
+    launch_label_scatter(c->stream, c->d_obj, c->N, F, T, To, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src, 0, nullptr);
     return CD_OK;
 }
 
@@ -493,36 +525,86 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     st = sync_fs(c, F);   // sync #4: n_plane, n_o, n_k, ksize, koff
     if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    // Every cluster of every frame gets its ICP (opd.cpp:376-413).  The device extracts the ICP sources KICP clusters per
+    // frame at a time; frames with more than KICP clusters (rare) need further rounds, and the host needs their sizes.
+    int kmax = 0, ncl = 0;
+    long long cl_points = 0;
+    std::vector<int> first_cl((size_t)F + 1, 0);
+    for (int f = 0; f < F; ++f) {
+        first_cl[(size_t)f] = ncl;
+        ncl += c->h_fs[f].n_k;
+        kmax = std::max(kmax, c->h_fs[f].n_k);
+    }
+    first_cl[(size_t)F] = ncl;
+    std::vector<int> csize((size_t)std::max(ncl, 1)), coff((size_t)std::max(ncl, 1));   // size / source offset of every cluster
+    for (int f = 0; f < F; ++f) {
+        const FrameState& s = c->h_fs[f];
+        int* sz = csize.data() + first_cl[(size_t)f];
+        if (s.n_k > KICP) HIPCHK(c, hipMemcpyAsync(sz, c->d_sizes + (size_t)f * c->N, sizeof(int) * (size_t)s.n_k, hipMemcpyDeviceToHost, c->stream));
+        else for (int k = 0; k < s.n_k; ++k) sz[k] = s.ksize[k];
+    }
+    const int rounds_k = std::max(1, (kmax + KICP - 1) / KICP);
+    if (rounds_k > 1) HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < F; ++f) {
+        int off = 0;
+        for (int k = first_cl[(size_t)f]; k < first_cl[(size_t)f + 1]; ++k) { coff[(size_t)k] = off; off += csize[(size_t)k]; cl_points += csize[(size_t)k]; }
+    }
+    st = ensure_clusters(c, ncl, cl_points);
+    if (st) return st;
+    int max_no2 = 0;
+    for (int f = 0; f < F; ++f) max_no2 = std::max(max_no2, c->h_fs[f].n_o);
+    const int To2 = std::max(1, (max_no2 + TILE - 1) / TILE);
+    if (rounds_k > 1) {   // offsets of the later rounds' clusters, [round][F][KICP]
+        const size_t need = (size_t)rounds_k * F * KICP;
+        if (need > c->koffx_cap) {
+            if (c->d_koffx) hipFree(c->d_koffx);
+            c->d_koffx = nullptr; c->koffx_cap = 0;
+            HIPCHK(c, dalloc(&c->d_koffx, need));
+            c->koffx_cap = need;
+        }
+        std::vector<int> tab(need, 0);
+        for (int r = 1; r < rounds_k; ++r)
+            for (int f = 0; f < F; ++f)
+                for (int k = 0; k < KICP; ++k) {
+                    const int q = first_cl[(size_t)f] + r * KICP + k;
+                    if (q < first_cl[(size_t)f + 1]) tab[((size_t)r * F + f) * KICP + k] = coff[(size_t)q];
+                }
+        HIPCHK(c, copy_sync(c, c->d_koffx, tab.data(), sizeof(int) * need, hipMemcpyHostToDevice));
+    }
+    // (re)build the ICP sources d_src0 / d_src of every round.  Round 0 was extracted by stage_cluster; it is redone only
+    // when d_src has been consumed by a previous template pass or d_tileK by a later round.
+    auto extract_sources = [&](bool redo_round0) -> int {
+        for (int r = redo_round0 ? 0 : 1; r < rounds_k; ++r) {
+            if (r > 0 || rounds_k > 1) {
+                HIPCHK(c, hipMemsetAsync(c->d_tileK, 0, sizeof(int) * (size_t)F * KICP * c->T, c->stream));
+                launch_label_count(c->stream, c->N, F, c->T, To2, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK, r * KICP);
+                launch_scan_tiles(c->stream, c->d_tileK, F * KICP, c->T, nullptr, 0);
+            }
+            launch_label_scatter(c->stream, c->d_obj, c->N, F, c->T, To2, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src, r * KICP,
+                                 r > 0 ? c->d_koffx + (size_t)r * F * KICP : nullptr);
+        }
+        return CD_OK;
+    };
     // ICP problems.  template_slot >= 0: every cluster against that slot.  template_slot == -1: every cluster
     // against every loaded template, one ICP pass per slot; the result with the lowest fitness is kept
-    // (ties -> lowest slot).  k_label_scatter is re-run between passes to restore the untransformed sources.
+    // (ties -> lowest slot).  The sources are re-extracted between passes (ICP transforms d_src in place).
     std::vector<int> slots;
     if (p->template_slot >= 0) slots.push_back(p->template_slot);
     else for (int sidx = 0; sidx < CD_MAX_TEMPLATES; ++sidx) if (c->tpl_m[sidx] > 0) slots.push_back(sidx);
     if (slots.empty()) slots.push_back(0);
-    int ncl = 0;
-    std::vector<int> first_cl(F, 0);
-    for (int f = 0; f < F; ++f) {
-        first_cl[f] = ncl;
-        ncl += std::min(c->h_fs[f].n_k, KICP);
-    }
-    std::vector<cd_cluster_result> best((size_t)std::max(ncl, 1));
+    std::vector<cd_cluster_result>& best = c->last_clusters;
+    best.assign((size_t)std::max(ncl, 1), cd_cluster_result());
     long long pairs = 0;
     for (size_t si = 0; si < slots.size(); ++si) {
         const int slot = slots[si];
-        if (si > 0) {
-            int max_no2 = 0;
-            for (int f = 0; f < F; ++f) max_no2 = std::max(max_no2, c->h_fs[f].n_o);
-            launch_label_scatter(c->stream, c->d_obj, c->N, F, c->T, std::max(1, (max_no2 + TILE - 1) / TILE), c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src);
-        }
+        st = extract_sources(si > 0);
+        if (st) return st;
         int q = 0;
         for (int f = 0; f < F; ++f) {
-            const FrameState& s = c->h_fs[f];
-            const int kk = std::min(s.n_k, KICP);
-            for (int k = 0; k < kk; ++k) {
-                IcpCluster& cl = c->h_cl[q++];
-                cl.src_off = f * c->N + s.koff[k];
-                cl.n = s.ksize[k];
+            for (int k = 0; k < c->h_fs[f].n_k; ++k, ++q) {
+                IcpCluster& cl = c->h_cl[q];
+                cl.src_off = f * c->N + coff[(size_t)q];
+                cl.n = csize[(size_t)q];
                 cl.frame = f;
                 cl.k = k;
                 cl.tpl_off = c->tpl_off[slot];
@@ -542,6 +624,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
             if (si == 0 || r.fitness < best[(size_t)k].fitness) best[(size_t)k] = r;
         }
     }
+    c->last_first = first_cl;
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // records
     long long balg = 0;
@@ -555,14 +638,15 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
         r.n_plane = s.n_plane;
         r.n_objects = s.n_o;
         r.n_clusters = s.n_k;
+        r.flags = s.n_k > KICP ? CD_FRAME_MORE_CLUSTERS : 0;
         r.ransac_iterations = iterations[f];
         if (s.status == CD_OK && !c->h_have[f]) r.status = CD_ERR_NO_MODEL;
         if (c->h_have[f]) { r.plane[0] = c->h_model[f].x; r.plane[1] = c->h_model[f].y; r.plane[2] = c->h_model[f].z; r.plane[3] = c->h_model[f].w; }
-        const int kk = std::min(s.n_k, KICP);
         balg += 12ll * N + 12ll * s.n_v + 12ll * s.n_v * (rounds + 3) + 4ll * s.n_v + 16ll * s.n_o + 200ll * s.n_k;
-        for (int k = 0; k < kk; ++k) {
-            r.clusters[k] = best[(size_t)(first_cl[f] + k)];
-            const long long b = 12ll * c->tpl_m[r.clusters[k].template_slot] + 12ll * s.ksize[k] * (r.clusters[k].iterations + 1);
+        for (int k = 0; k < s.n_k; ++k) {
+            const cd_cluster_result& cr = best[(size_t)(first_cl[(size_t)f] + k)];
+            if (k < KICP) r.clusters[k] = cr;
+            const long long b = 12ll * c->tpl_m[cr.template_slot] + 12ll * cr.size * (cr.iterations + 1);
             balg += b;
             c->timing.icp_algorithmic_bytes += b;
         }
@@ -645,6 +729,7 @@ void cd_destroy(cd_context* c) {
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
+    if (c->d_koffx) hipFree(c->d_koffx);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -696,6 +781,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
     }
     const size_t ncl = F * KICP;
+    c->cl_cap = (int)ncl;
     c->work_cap = (int)(F * (N / 64 + KICP + 1));
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
@@ -1133,6 +1219,18 @@ int cd_process_batch(cd_context* c, const void* frames, size_t stride, int point
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->d_in, frames, bytes, hipMemcpyHostToDevice, c->stream));
     return process_batch_impl(c, c->d_in, stride, points_per_frame, n_frames, p, results, plane_inliers, labels);
+}
+
+int cd_get_cluster_results(const cd_context* c, int frame, int first, int capacity, cd_cluster_result* out, int* out_total) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    if (out_total) *out_total = 0;
+    if (frame < 0 || first < 0 || capacity < 0 || (capacity > 0 && !out)) return CD_ERR_INVALID_ARG;
+    if ((size_t)frame + 1 >= c->last_first.size()) return CD_ERR_INVALID_ARG;   // not a frame of the last batch
+    const int lo = c->last_first[(size_t)frame], hi = c->last_first[(size_t)frame + 1];
+    if (out_total) *out_total = hi - lo;
+    int n = 0;
+    for (int k = lo + first; k < hi && n < capacity; ++k) out[n++] = c->last_clusters[(size_t)k];
+    return n;
 }
 
 int cd_get_timing(const cd_context* c, cd_timing* out) {

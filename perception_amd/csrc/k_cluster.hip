@@ -321,13 +321,16 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __res
     }
 }
 
+// Clusters are extracted for ICP KICP at a time: round `kbase` handles the clusters ranked kbase .. kbase+KICP-1 (a frame
+// rarely has more than KICP; the host runs further rounds only for frames that do - opd.cpp:376 gives EVERY cluster its ICP).
 __global__ void __launch_bounds__(BLOCK) k_label_count(int N, int T, const FrameState* __restrict__ fs, int enable,
                                                        const int* __restrict__ parent, const int* __restrict__ rank_of_root,
-                                                       int* __restrict__ label, int* __restrict__ tile_cnt) {
+                                                       int* __restrict__ label, int* __restrict__ tile_cnt, int kbase) {
     __shared__ int s_c[WAVES_PER_BLOCK][KICP];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_o;
     if (tile * TILE >= n) return;
+    if (kbase > 0 && kbase >= fs[f].n_k) return;
     const size_t fbase = (size_t)f * N;
     const int base = tile * TILE + w * WAVE_SPAN + lane;
     int cnt[KICP];
@@ -339,10 +342,10 @@ __global__ void __launch_bounds__(BLOCK) k_label_count(int N, int T, const Frame
         int lab = -1;
         if (e < n) {
             lab = enable ? rank_of_root[fbase + parent[fbase + e]] : 0;
-            label[fbase + e] = lab;
+            if (kbase == 0) label[fbase + e] = lab;
         }
 #pragma unroll
-        for (int k = 0; k < KICP; ++k) cnt[k] += __popcll(__ballot(lab == k));
+        for (int k = 0; k < KICP; ++k) cnt[k] += __popcll(__ballot(lab == kbase + k));
     }
     if (lane == 0) {
 #pragma unroll
@@ -355,14 +358,16 @@ __global__ void __launch_bounds__(BLOCK) k_label_count(int N, int T, const Frame
     }
 }
 
+// koff_tab: offsets of the round's clusters in the frame's ICP source segment, [F][KICP] (NULL in round 0: fs[f].koff)
 __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restrict__ obj, int N, int T,
                                                          const FrameState* __restrict__ fs, const int* __restrict__ label,
                                                          const int* __restrict__ tile_off, float4* __restrict__ src0,
-                                                         float4* __restrict__ src) {
+                                                         float4* __restrict__ src, int kbase, const int* __restrict__ koff_tab) {
     __shared__ int s_c[WAVES_PER_BLOCK][KICP];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_o;
     if (tile * TILE >= n) return;
+    if (kbase > 0 && kbase >= fs[f].n_k) return;
     const size_t fbase = (size_t)f * N;
     const int base = tile * TILE + w * WAVE_SPAN + lane;
     int lab[ITEMS];
@@ -372,7 +377,7 @@ __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restric
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
-        lab[j] = e < n ? label[fbase + e] : -1;
+        lab[j] = e < n ? label[fbase + e] - kbase : -1;   // rank within the round (other rounds' clusters fall outside 0..KICP-1)
 #pragma unroll
         for (int k = 0; k < KICP; ++k) cnt[k] += __popcll(__ballot(lab[j] == k));
     }
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restric
     int pos[KICP];
 #pragma unroll
     for (int k = 0; k < KICP; ++k) {
-        int p = fs[f].koff[k] + tile_off[((size_t)f * KICP + k) * T + tile];
+        int p = (koff_tab ? koff_tab[f * KICP + k] : fs[f].koff[k]) + tile_off[((size_t)f * KICP + k) * T + tile];
         for (int q = 0; q < w; ++q) p += s_c[q][k];
         pos[k] = p;
     }
@@ -435,13 +440,14 @@ void launch_cluster_rank(hipStream_t s, int N, int F, FrameState* fs, int enable
                        rank_of_root, sizes_sorted);
 }
 void launch_label_count(hipStream_t s, int N, int F, int T, int Tact, const FrameState* fs, int enable, const int* parent,
-                        const int* rank_of_root, int* label, int* tile_cnt) {
+                        const int* rank_of_root, int* label, int* tile_cnt, int kbase) {
     hipLaunchKernelGGL(k_label_count, dim3(Tact, F), dim3(BLOCK), 0, s, N, T, fs, enable, parent, rank_of_root, label,
-                       tile_cnt);
+                       tile_cnt, kbase);
 }
 void launch_label_scatter(hipStream_t s, const float4* obj, int N, int F, int T, int Tact, const FrameState* fs,
-                          const int* label, const int* tile_off, float4* src0, float4* src) {
-    hipLaunchKernelGGL(k_label_scatter, dim3(Tact, F), dim3(BLOCK), 0, s, obj, N, T, fs, label, tile_off, src0, src);
+                          const int* label, const int* tile_off, float4* src0, float4* src, int kbase, const int* koff_tab) {
+    hipLaunchKernelGGL(k_label_scatter, dim3(Tact, F), dim3(BLOCK), 0, s, obj, N, T, fs, label, tile_off, src0, src, kbase,
+                       koff_tab);
 }
 
 }  // namespace cd

@@ -45,9 +45,9 @@ void launch_cluster_flatten(hipStream_t s, int N, int F, int Tact, const FrameSt
 void launch_cluster_rank(hipStream_t s, int N, int F, FrameState* fs, int enable, int min_sz, int max_sz,
                          const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted);
 void launch_label_count(hipStream_t s, int N, int F, int T, int Tact, const FrameState* fs, int enable, const int* parent,
-                        const int* rank_of_root, int* label, int* tile_cnt);
+                        const int* rank_of_root, int* label, int* tile_cnt, int kbase);
 void launch_label_scatter(hipStream_t s, const float4* obj, int N, int F, int T, int Tact, const FrameState* fs,
-                          const int* label, const int* tile_off, float4* src0, float4* src);
+                          const int* label, const int* tile_off, float4* src0, float4* src, int kbase, const int* koff_tab);
 
 // k_icp.hip
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,

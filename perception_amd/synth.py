@@ -80,6 +80,26 @@ def scene_for(index, k_obj=None, seed=None):
     return dict(seed=seed, n=n, p0=p0, e1=e1, e2=e2, boxes=boxes)
 
 
+def scene_grid(index, cols=4, rows=3, dims=(0.05, 0.05, 0.03), pitch=(0.085, 0.085), jitter=0.3):
+    """The table of frame `index` with cols x rows small cuboids on it (sizes jittered so that the clusters differ in size):
+    more clusters than the CD_MAX_CLUSTERS_PER_FRAME slots of a record, which object_pose_detection.cpp:376 all registers."""
+    sc = scene_for(index, k_obj=0)
+    u = _uniform(sc["seed"], 11, 4 * cols * rows)
+    n, e1, e2, p0 = sc["n"], sc["e1"], sc["e2"], sc["p0"]
+    boxes = []
+    for r in range(rows):
+        for c in range(cols):
+            k = r * cols + c
+            L, W, H = (d * (1.0 + jitter * (u[4 * k + j] - 0.5)) for j, d in enumerate(dims))
+            yaw = np.deg2rad(30.0 * (u[4 * k + 3] - 0.5))
+            ex = np.cos(yaw) * e1 + np.sin(yaw) * e2
+            ey = np.cross(n, ex)
+            ctr = p0 + (c - (cols - 1) / 2.0) * pitch[0] * e1 + (r - (rows - 1) / 2.0) * pitch[1] * e2 + (H / 2.0) * n
+            boxes.append(dict(R=np.stack([ex, ey, n], axis=1), c=ctr, half=np.array([L, W, H]) / 2.0, yaw=yaw))
+    sc["boxes"] = boxes
+    return sc
+
+
 _RAY_CACHE = {}
 
 

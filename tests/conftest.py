@@ -4,6 +4,11 @@ import sys
 import numpy as np
 import pytest
 
+# The PyTorch-ROCm wheel bundles its own HIP runtime with the same SONAME (libamdhip64.so.7) as the system one that
+# libcuboid_hip.so links: a process gets ONE copy, whichever is loaded first, and torch cannot initialise on the system
+# copy ("No HIP GPUs are available").  Tests that use both (device-resident inputs, RCCL) need torch's copy: load it first.
+import torch  # noqa: F401,E402
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -12,6 +17,23 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(autouse=True)
+def _no_hip_error_left_behind(request):
+    """After every GPU test: the library must not leave a failed HIP call unreported (hipGetLastError is sticky per host
+    thread; an error that libcuboid_hip.so ignored would surface later in some unrelated torch call)."""
+    yield
+    if request.node.get_closest_marker("gpu") is None:
+        return
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so.7")
+    except OSError:
+        return
+    hip.hipGetErrorString.restype = ctypes.c_char_p
+    err = hip.hipGetLastError()
+    assert err == 0, "a HIP call failed silently during this test: %d (%s)" % (err, hip.hipGetErrorString(err).decode())
 
 
 @pytest.fixture(scope="session")

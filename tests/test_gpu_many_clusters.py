@@ -1,0 +1,92 @@
+"""Every cluster of a frame gets its ICP, however many there are (object_detection/src/object_pose_detection.cpp:376-413
+loops over ALL of object_cluster_indices and :416-423 picks among all of them).  The fixed-size record holds the
+CD_MAX_CLUSTERS_PER_FRAME largest and flags the rest, which cd_get_cluster_results returns."""
+import numpy as np
+import pytest
+
+from perception_amd import capi, synth, templates
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, tag):
+    assert (a.size, a.iterations, a.converged, a.accepted, a.template_slot) == (b.size, b.iterations, b.converged, b.accepted, b.template_slot), tag
+    assert list(a.T) == list(b.T) and a.fitness == b.fitness, tag
+    assert np.linalg.norm(np.array(a.pose) - np.array(b.pose)) < 1e-4, tag
+
+
+@pytest.fixture(scope="module")
+def small_tpl():
+    return templates.template_xyz32(0.05, 0.05, 0.03, 0.002)
+
+
+@pytest.mark.parametrize("mode", ["auto", "sliced", "cluster", "pipe"])
+def test_twelve_clusters_all_registered(O, small_tpl, mode, monkeypatch):
+    if mode != "auto":
+        monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    frame = synth.render(synth.scene_grid(3))
+    prm = capi.default_params()
+    prm.cluster_min_size = 60
+    o = O.process_frame(frame, prm, small_tpl, all_clusters=64)
+    ro = o["result"]
+    assert ro.n_clusters == 12 and len(o["clusters"]) == 12 and ro.flags == capi.CD_FRAME_MORE_CLUSTERS
+    ctx = capi.Context(max_points=frame.shape[0], max_frames=1)
+    try:
+        ctx.set_template(0, small_tpl)
+        res, pi, lb = ctx.process_batch(frame[None], prm, want_indices=True)
+        r = res[0]
+        assert (r.n_cropped, r.n_voxels, r.n_plane, r.n_objects, r.n_clusters, r.flags) == \
+               (ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters, ro.flags)
+        assert np.array_equal(lb[0][:r.n_objects], o["labels"])
+        allg = ctx.cluster_results(0)
+        assert len(allg) == 12
+        for k in range(12):
+            _same(allg[k], o["clusters"][k], (mode, k))
+        for k in range(capi.CD_MAX_CLUSTERS_PER_FRAME):
+            _same(r.clusters[k], o["clusters"][k], (mode, "record", k))
+        # windowed reads and argument errors of cd_get_cluster_results
+        part = ctx.cluster_results(0, first=9, count=2)
+        assert [c.size for c in part] == [c.size for c in o["clusters"][9:11]]
+        assert ctx.cluster_results(0, first=12) == []
+        with pytest.raises(capi.CuboidError):
+            ctx.cluster_results(1)
+        # opd.cpp:416-423: the cluster whose size is closest to the template's may be ranked 9th or later
+        m = 190
+        diffs = [abs(c.size - m) for c in allg]
+        assert int(np.argmin(diffs)) >= capi.CD_MAX_CLUSTERS_PER_FRAME
+    finally:
+        ctx.close()
+
+
+def test_batch_with_mixed_cluster_counts_and_two_templates(O, small_tpl, template):
+    """Frames with 12, 1-3 and 12 clusters in one batch (the later extraction rounds only touch the frames that need them),
+    and template_slot = -1: every cluster against both templates, sources re-extracted between the two ICP passes."""
+    frames = np.stack([synth.render(synth.scene_grid(3)), synth.frame(1), synth.render(synth.scene_grid(5, cols=3, rows=3)), synth.frame(2)], 0)
+    prm = capi.default_params()
+    prm.cluster_min_size = 60
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, small_tpl)
+        ctx.set_template(1, template)
+        for slot in (0, 1, -1):
+            prm.template_slot = slot
+            res, _, _ = ctx.process_batch(frames, prm)
+            for f in range(len(frames)):
+                per = {}
+                for s_, tp in ((0, small_tpl), (1, template)):
+                    prm.template_slot = s_
+                    per[s_] = O.process_frame(frames[f], prm, tp, all_clusters=64)
+                prm.template_slot = slot
+                got = ctx.cluster_results(f)
+                assert len(got) == res[f].n_clusters == per[0]["result"].n_clusters
+                for k, g in enumerate(got):
+                    want_slot = slot if slot >= 0 else min((0, 1), key=lambda s_: (per[s_]["clusters"][k].fitness, s_))
+                    w = per[want_slot]["clusters"][k]
+                    assert g.template_slot == want_slot
+                    assert (g.size, g.iterations, g.converged) == (w.size, w.iterations, w.converged), (slot, f, k)
+                    assert list(g.T) == list(w.T) and g.fitness == w.fitness, (slot, f, k)
+                    if k < capi.CD_MAX_CLUSTERS_PER_FRAME:
+                        assert list(res[f].clusters[k].T) == list(w.T)
+        assert res[0].flags == capi.CD_FRAME_MORE_CLUSTERS and res[1].flags == 0
+    finally:
+        ctx.close()
