@@ -1054,6 +1054,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    (void)wave;
     // every cluster of one launch uses the same (LDS-resident, gridded) template - the host guarantees it
     const IcpCluster c0 = cl[order[0]];
     const IcpGrid g = grids[c0.slot];
@@ -1310,7 +1311,6 @@ void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpClust
                         const unsigned short* tcell, float4* src, const float4* src0, int* nn,
                         int* queue, int n_cu, IcpParams prm) {
     if (ncl <= 0) return;
-    hipMemsetAsync(queue, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_icp_cluster, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
                        grids, tcell, src, src0, nn, queue, prm);
 }
@@ -1320,7 +1320,6 @@ void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster*
                      const unsigned short* tcell, float4* src, const float4* src0, int* nn,
                      int* queue, int n_cu, IcpParams prm) {
     if (ncl <= 0) return;
-    hipMemsetAsync(queue, 0, sizeof(int), s);
     hipLaunchKernelGGL(k_icp_pipe, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
                        kdmap, grids, tcell, src, src0, nn, queue, prm);
 }

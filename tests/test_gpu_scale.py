@@ -226,3 +226,33 @@ def test_whole_cluster_drivers_on_odd_sizes(O, template, mode, monkeypatch):
             assert list(res.T) == list(r0.T) and res.fitness == r0.fitness, (mode, n)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_template_arena_is_reclaimed(O, template):
+    """cd_set_template on the same slot with ever larger templates: the space of the replaced ones is reclaimed (the arena
+    holds 2^18 points; 45 templates of ~7000+ points would not fit side by side), other slots survive the re-packing, and
+    ICP against the re-packed templates still gives the oracle's bits."""
+    from conftest import rot_xyz
+    rng = np.random.default_rng(5)
+    ctx = capi.Context(max_points=8192, max_frames=1)
+    try:
+        small = templates.template_xyz32(0.05, 0.05, 0.03, 0.002)
+        ctx.set_template(3, small)
+        for i in range(45):
+            grown = np.concatenate([template, template[: 64 * (i + 1)] + np.float32(0.3)])
+            ctx.set_template(0, grown)
+        prm = capi.default_params()
+        prm.icp_max_iterations = 30
+        for slot, tpl in ((0, grown), (3, small)):
+            idx = rng.integers(0, len(tpl), 900)
+            src = (tpl[idx] @ rot_xyz(0.02, -0.03, 0.04).T + np.float32(0.002)).astype(np.float32)
+            st, res, _ = ctx.icp(slot, src, prm)
+            s0, r0, _ = O.icp(tpl, src, prm, nn_mode=1)
+            assert st == s0 == 0 and res.iterations == r0.iterations
+            assert list(res.T) == list(r0.T) and res.fitness == r0.fitness
+        with pytest.raises(capi.CuboidError) as e:          # genuinely too large
+            ctx.set_template(1, np.zeros((300000, 3), np.float32))
+        assert e.value.status == capi.CD_ERR_CAPACITY
+    finally:
+        ctx.close()
