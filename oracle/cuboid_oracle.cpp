@@ -54,6 +54,24 @@ namespace {
 constexpr int FIX_SHIFT = 32;     // C4: coordinates and products
 constexpr int FIX_SHIFT_D2 = 36;  // C4: squared distances
 
+// Arithmetic variants (orc_process_frame_arith).  The canonical rules C2/C4 pick ONE of the results real PCL can produce
+// (its summation orders are implementation-defined); these switches evaluate another plausible one, so that the tests can
+// MEASURE how far the canonical choice can sit from a PCL execution (real PCL is not available here):
+//   ARITH_SEQUENTIAL   the long reductions as PCL/Eigen's scalar code would run them: plane-refit moments as float32
+//                      running sums in inlier order (computeMeanAndCovarianceMatrix), ICP means and covariance as
+//                      pcl::umeyama does (float32 sums, demeaned float32 products), MSE and fitness as double running
+//                      sums of float32 squared distances (calculateMSE, getFitnessScore)
+//   ARITH_REVERSE_TIES VoxelGrid's std::sort leaves equal keys in an unspecified order: sum every voxel in DESCENDING
+//                      input order instead of ascending
+//   ARITH_PROBE        canonical run that ALSO evaluates, from the same inputs at every step, what the sequential arithmetic
+//                      would have produced, and records the largest single-step differences in t_probe: [0] Frobenius
+//                      difference of the 4x4 ICP step transform, [1] max |difference| of the refitted plane coefficients,
+//                      [2] relative difference of the correspondence MSE, [3] of the fitness score
+enum { ARITH_SEQUENTIAL = 1, ARITH_REVERSE_TIES = 2, ARITH_PROBE = 4 };
+static thread_local int t_arith = 0;
+static thread_local double t_probe[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // [4] step transform incl. ill-conditioned steps, [5] their count, [6] steps
+static thread_local float t_last_sv[3] = {0, 0, 0};   // singular values of the last umeyama covariance
+
 inline float ldf(const uint8_t* p) {
     float f;
     std::memcpy(&f, p, 4);
@@ -152,6 +170,14 @@ int voxel_grid(const Cloud& c, const std::vector<int>& idx, float leaf, int rgb_
                      [](const std::pair<int, int>& a, const std::pair<int, int>& b) {
                          return a.first < b.first;
                      });
+    if (t_arith & ARITH_REVERSE_TIES) {   // the other extreme of what an unstable sort may leave
+        for (size_t a0 = 0; a0 < kv.size();) {
+            size_t a1 = a0 + 1;
+            while (a1 < kv.size() && kv[a1].first == kv[a0].first) ++a1;
+            std::reverse(kv.begin() + a0, kv.begin() + a1);
+            a0 = a1;
+        }
+    }
     size_t first = 0;
     while (first < kv.size()) {
         size_t last = first + 1;
@@ -350,6 +376,30 @@ void plane_refit(const float* P, const std::vector<int>& inl, const float model[
     float accu[9];
     const double n = (double)inl.size();
     for (int k = 0; k < 9; ++k) accu[k] = (float)(unfix((int64_t)S[k], FIX_SHIFT) / n);
+    if (t_arith & ARITH_PROBE) {
+        float alt[4];
+        const int keep = t_arith;
+        t_arith = (keep & ~ARITH_PROBE) | ARITH_SEQUENTIAL;
+        plane_refit(P, inl, model, alt);
+        t_arith = keep;
+        float can[4];
+        t_arith = keep & ~(ARITH_PROBE | ARITH_SEQUENTIAL);
+        plane_refit(P, inl, model, can);
+        t_arith = keep;
+        // eigenvector sign is not oriented: compare up to a common sign
+        double d0 = 0, d1 = 0;
+        for (int k = 0; k < 4; ++k) { d0 = std::max(d0, (double)std::fabs(can[k] - alt[k])); d1 = std::max(d1, (double)std::fabs(can[k] + alt[k])); }
+        t_probe[1] = std::max(t_probe[1], std::min(d0, d1));
+    }
+    if (t_arith & ARITH_SEQUENTIAL) {   // pcl::computeMeanAndCovarianceMatrix as written: float32 running sums, one division
+        float acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i : inl) {
+            const float x = P[3 * (size_t)i], y = P[3 * (size_t)i + 1], z = P[3 * (size_t)i + 2];
+            acc[0] += x * x; acc[1] += x * y; acc[2] += x * z; acc[3] += y * y; acc[4] += y * z; acc[5] += z * z;
+            acc[6] += x; acc[7] += y; acc[8] += z;
+        }
+        for (int k = 0; k < 9; ++k) accu[k] = acc[k] / (float)inl.size();
+    }
     float cov[3][3];
     cov[0][0] = accu[0] - accu[6] * accu[6];
     cov[0][1] = accu[1] - accu[6] * accu[7];
@@ -778,20 +828,11 @@ inline float det3(const float m[3][3]) {
            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
 
-// pcl::umeyama(src, dst, with_scaling=false) fed with the fixed-point moments (C4)
-void umeyama_from_moments(const uint64_t Sp[3], const uint64_t Sq[3], const uint64_t Sqp[9], int n,
-                          float T[16]) {
-    double mp[3], mq[3];
-    for (int a = 0; a < 3; ++a) {
-        mp[a] = unfix((int64_t)Sp[a], FIX_SHIFT) / (double)n;
-        mq[a] = unfix((int64_t)Sq[a], FIX_SHIFT) / (double)n;
-    }
-    float sigma[3][3];
-    for (int a = 0; a < 3; ++a)
-        for (int b = 0; b < 3; ++b)
-            sigma[a][b] = (float)(unfix((int64_t)Sqp[3 * a + b], FIX_SHIFT) / (double)n - mq[a] * mp[b]);
+// pcl::umeyama(src, dst, with_scaling=false) from the means and the covariance: SVD, reflection handling, R, t
+void umeyama_from_sigma(const float mpf[3], const float mqf[3], const float sigma[3][3], float T[16]) {
     float U[3][3], S[3], V[3][3];
     jacobi_svd3(sigma, U, S, V);
+    t_last_sv[0] = S[0]; t_last_sv[1] = S[1]; t_last_sv[2] = S[2];
     float sd[3] = {1.f, 1.f, 1.f};
     if (det3(sigma) < 0.f) sd[2] = -1.f;
     int rank = 0;
@@ -814,14 +855,51 @@ void umeyama_from_moments(const uint64_t Sp[3], const uint64_t Sq[3], const uint
     } else {
         usvt(sd);
     }
-    const float mpf[3] = {(float)mp[0], (float)mp[1], (float)mp[2]};
-    const float mqf[3] = {(float)mq[0], (float)mq[1], (float)mq[2]};
     for (int i = 0; i < 16; ++i) T[i] = 0.f;
     for (int i = 0; i < 3; ++i) {
         for (int j = 0; j < 3; ++j) T[4 * i + j] = R[i][j];
         T[4 * i + 3] = mqf[i] - ((R[i][0] * mpf[0] + R[i][1] * mpf[1]) + R[i][2] * mpf[2]);
     }
     T[15] = 1.f;
+}
+
+// ... fed with the fixed-point moments (C4)
+void umeyama_from_moments(const uint64_t Sp[3], const uint64_t Sq[3], const uint64_t Sqp[9], int n,
+                          float T[16]) {
+    double mp[3], mq[3];
+    for (int a = 0; a < 3; ++a) {
+        mp[a] = unfix((int64_t)Sp[a], FIX_SHIFT) / (double)n;
+        mq[a] = unfix((int64_t)Sq[a], FIX_SHIFT) / (double)n;
+    }
+    float sigma[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b)
+            sigma[a][b] = (float)(unfix((int64_t)Sqp[3 * a + b], FIX_SHIFT) / (double)n - mq[a] * mp[b]);
+    const float mpf[3] = {(float)mp[0], (float)mp[1], (float)mp[2]};
+    const float mqf[3] = {(float)mq[0], (float)mq[1], (float)mq[2]};
+    umeyama_from_sigma(mpf, mqf, sigma, T);
+}
+
+// ... as pcl::umeyama's own code runs it in scalar float32 (ARITH_SEQUENTIAL): src_mean = src.rowwise().sum() * (1/n),
+// the clouds demeaned, sigma = (1/n) * dst_demean * src_demean^T, every sum a float32 running sum in point order
+void umeyama_sequential(const float* P, const float* Q, int n, float T[16]) {
+    const float one_over_n = 1.0f / (float)n;
+    float sp[3] = {0, 0, 0}, sq[3] = {0, 0, 0};
+    for (int i = 0; i < n; ++i)
+        for (int a = 0; a < 3; ++a) { sp[a] += P[3 * (size_t)i + a]; sq[a] += Q[3 * (size_t)i + a]; }
+    float mp[3], mq[3];
+    for (int a = 0; a < 3; ++a) { mp[a] = sp[a] * one_over_n; mq[a] = sq[a] * one_over_n; }
+    float acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+    for (int i = 0; i < n; ++i) {
+        float dp[3], dq[3];
+        for (int a = 0; a < 3; ++a) { dp[a] = P[3 * (size_t)i + a] - mp[a]; dq[a] = Q[3 * (size_t)i + a] - mq[a]; }
+        for (int a = 0; a < 3; ++a)
+            for (int b = 0; b < 3; ++b) acc[a][b] += dq[a] * dp[b];
+    }
+    float sigma[3][3];
+    for (int a = 0; a < 3; ++a)
+        for (int b = 0; b < 3; ++b) sigma[a][b] = one_over_n * acc[a][b];
+    umeyama_from_sigma(mp, mq, sigma, T);
 }
 
 inline void xform(const float T[16], const float* p, float* o) {
@@ -893,17 +971,21 @@ int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int
         }
     };
     std::vector<float>& X = out.aligned;
+    std::vector<float> Qseq;
     double prev_mse = std::numeric_limits<double>::max();
     const double rot_thr = 1.0 - trans_eps;  // setRotationThreshold(1.0 - transformation_epsilon_)
     const double abs_mse_thr = 1e-12;        // DefaultConvergenceCriteria default
     for (;;) {
         uint64_t Sp[3] = {0, 0, 0}, Sq[3] = {0, 0, 0}, Sqp[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Sd = 0;
+        double mse_seq = 0.0;               // ARITH_SEQUENTIAL: calculateMSE's double running sum
+        if (t_arith & (ARITH_SEQUENTIAL | ARITH_PROBE)) Qseq.resize(3 * (size_t)n);
         for (int i = 0; i < n; ++i) {
             const float* p = X.data() + 3 * (size_t)i;
             float d;
             int j;
             nn(p, d, j);
             const float* q = tgt + 3 * (size_t)j;
+            if (t_arith & (ARITH_SEQUENTIAL | ARITH_PROBE)) { mse_seq += (double)d; std::memcpy(&Qseq[3 * (size_t)i], q, 12); }
             for (int a = 0; a < 3; ++a) {
                 Sp[a] += (uint64_t)fix(p[a], FIX_SHIFT);
                 Sq[a] += (uint64_t)fix(q[a], FIX_SHIFT);
@@ -912,7 +994,23 @@ int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int
             Sd += (uint64_t)fix(d, FIX_SHIFT_D2);
         }
         float T[16];
-        umeyama_from_moments(Sp, Sq, Sqp, n, T);
+        if (t_arith & ARITH_SEQUENTIAL) umeyama_sequential(X.data(), Qseq.data(), n, T);
+        else umeyama_from_moments(Sp, Sq, Sqp, n, T);
+        if (t_arith & ARITH_PROBE) {   // same correspondences, the other arithmetic
+            // a covariance whose second singular value is (numerically) nothing leaves the rotation about the first axis to
+            // the rounding noise - in real PCL as much as here (iteration 0 from the identity guess, half a metre away, maps
+            // the whole cluster onto one corner of the template): such steps are counted, not compared
+            const bool well = t_last_sv[1] > 1.0e-3f * t_last_sv[0] && t_last_sv[0] > 0.f;
+            float Ts[16];
+            umeyama_sequential(X.data(), Qseq.data(), n, Ts);
+            double e = 0;
+            for (int i = 0; i < 16; ++i) e += ((double)T[i] - Ts[i]) * ((double)T[i] - Ts[i]);
+            t_probe[4] = std::max(t_probe[4], std::sqrt(e));
+            t_probe[6] += 1.0;
+            if (well) t_probe[0] = std::max(t_probe[0], std::sqrt(e)); else t_probe[5] += 1.0;
+            const double m_can = unfix((int64_t)Sd, FIX_SHIFT_D2) / (double)n, m_seq = mse_seq / (double)n;
+            if (m_can > 0) t_probe[2] = std::max(t_probe[2], std::fabs(m_can - m_seq) / m_can);
+        }
         for (int i = 0; i < n; ++i) {
             float o[3];
             xform(T, X.data() + 3 * (size_t)i, o);
@@ -933,7 +1031,7 @@ int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int
             out.converged = 1;
             break;
         }
-        const double mse = unfix((int64_t)Sd, FIX_SHIFT_D2) / (double)n;
+        const double mse = (t_arith & ARITH_SEQUENTIAL) ? mse_seq / (double)n : unfix((int64_t)Sd, FIX_SHIFT_D2) / (double)n;
         if (std::fabs(mse - prev_mse) < abs_mse_thr) {
             out.converged = 1;
             break;
@@ -946,14 +1044,20 @@ int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int
     }
     // getFitnessScore(): transform the ORIGINAL source by final_transformation_
     uint64_t Sf = 0;
+    double fit_seq = 0.0;
     for (int i = 0; i < n; ++i) {
         float o[3], d;
         int j;
         xform(out.T, src + 3 * (size_t)i, o);
         nn(o, d, j);
         Sf += (uint64_t)fix(d, FIX_SHIFT_D2);
+        fit_seq += (double)d;
     }
-    out.fitness = unfix((int64_t)Sf, FIX_SHIFT_D2) / (double)n;
+    out.fitness = (t_arith & ARITH_SEQUENTIAL) ? fit_seq / (double)n : unfix((int64_t)Sf, FIX_SHIFT_D2) / (double)n;
+    if (t_arith & ARITH_PROBE) {
+        const double f_can = unfix((int64_t)Sf, FIX_SHIFT_D2) / (double)n, f_seq = fit_seq / (double)n;
+        if (f_can > 0) t_probe[3] = std::max(t_probe[3], std::fabs(f_can - f_seq) / f_can);
+    }
     return CD_OK;
 }
 
@@ -1370,6 +1474,19 @@ int orc_process_frame_all(const void* pts, size_t stride, int n, const cd_params
         if (all_clusters && k < all_cap) { all_clusters[k] = cr; if (n_all) *n_all = k + 1; }
     }
     return CD_OK;
+}
+
+// the same chain under an arithmetic variant (ARITH_* bits): how far is the canonical result from another execution PCL allows?
+int orc_process_frame_arith(int arith, const void* pts, size_t stride, int n, const cd_params* prm, const void* tgt,
+                            size_t tstride, int m, int nn_mode, cd_frame_result* res, int32_t* plane_inliers,
+                            int32_t* labels, cd_cluster_result* all_clusters, int all_cap, int* n_all, double* probe /* 8 or NULL */) {
+    t_arith = arith;
+    for (double& v : t_probe) v = 0.0;
+    const int st = orc_process_frame_all(pts, stride, n, prm, tgt, tstride, m, nn_mode, res, plane_inliers, labels, nullptr, nullptr,
+                                         all_clusters, all_cap, n_all);
+    t_arith = 0;
+    if (probe) for (int k = 0; k < 8; ++k) probe[k] = t_probe[k];
+    return st;
 }
 
 int orc_process_frame(const void* pts, size_t stride, int n, const cd_params* prm, const void* tgt,

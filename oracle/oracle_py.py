@@ -179,6 +179,26 @@ def bbox_corners(H, l, w, h):
     return out
 
 
+ARITH_SEQUENTIAL, ARITH_REVERSE_TIES, ARITH_PROBE = 1, 2, 4
+
+
+def process_frame_arith(arith, points, prm, template, nn_mode=1, all_clusters=32):
+    """process_frame under an arithmetic variant (ARITH_* bits of cuboid_oracle.cpp): another execution real PCL's unspecified
+    summation / tie orders allow.  Returns dict(result, plane_inliers, labels, clusters)."""
+    a, st, n = _pts(points)
+    t, ts, m = _pts(template)
+    res = CdFrameResult()
+    pi = np.empty(max(n, 1), np.int32)
+    lb = np.empty(max(n, 1), np.int32)
+    allc = (CdClusterResult * max(all_clusters, 1))()
+    nall = C.c_int()
+    probe = np.zeros(8, np.float64)
+    s = lib().orc_process_frame_arith(int(arith), _p(a), st, n, C.byref(prm), _p(t), ts, m, nn_mode, C.byref(res), _p(pi), _p(lb),
+                                      allc, all_clusters, C.byref(nall), _p(probe))
+    return dict(status=s, result=res, plane_inliers=pi[:max(res.n_plane, 0)].copy(), labels=lb[:max(res.n_objects, 0)].copy(),
+                clusters=[allc[i] for i in range(nall.value)], probe=probe)
+
+
 def process_frame(points, prm, template, nn_mode=1, want_clouds=False, all_clusters=0):
     """One frame through the whole chain.  Returns dict(result, plane_inliers, labels[, voxels, objects][, clusters]).
     all_clusters = capacity of the list of per-cluster ICP results beyond the record's fixed slots (0: record only)."""

@@ -10,8 +10,11 @@ What it writes (all DATA, no reference source text):
                             still reproduces.
   template_cuboid_L200_W75_H100_3faces.pcd, template_cuboid_L200_W100_H75_3faces.pcd
                             the two small reference templates (data files, 46-50 KB).
-  marker_ascii.pcd, marker_ascii_tf.pcd, screwdriver_ascii.pcd, screwdriver_ascii_tf.pcd,
-  eraser_ascii.pcd          real D435 object clusters held by the reference (data files).
+  template_cuboid_L200_W100_H75.pcd
+                            the 21 400-point six-face template of an earlier generator version (data file, 578 KB):
+                            a real ICP target that does not fit the LDS image.
+  {marker,screwdriver,eraser,clamp}_ascii.pcd and *_ascii_tf.pcd
+                            real D435 object clusters held by the reference and their transformed copies (data files).
   transforms.json           the (translation, quaternion) values of transforms.txt.
   frames_golden.json        the ORACLE's outputs on synthetic frames 0..3 (so the GPU box,
                             which has no /root/reference, can check both the oracle and the
@@ -53,7 +56,8 @@ def reference_templates():
         for fn in sorted(os.listdir(tmp)):
             b = open(os.path.join(tmp, fn), "rb").read()
             out["make_cuboid_py"][fn] = {"sha256": sha(b), "bytes": len(b)}
-    for fn in ("template_cuboid_L200_W75_H100_3faces.pcd", "template_cuboid_L200_W100_H75_3faces.pcd"):
+    for fn in ("template_cuboid_L200_W75_H100_3faces.pcd", "template_cuboid_L200_W100_H75_3faces.pcd",
+               "template_cuboid_L200_W100_H75.pcd"):
         shutil.copyfile(os.path.join(tdir, fn), os.path.join(HERE, fn))
     return out
 
@@ -61,7 +65,7 @@ def reference_templates():
 def object_fixtures():
     odir = os.path.join(REF, "object_detection", "templates")
     for fn in ("marker_ascii.pcd", "marker_ascii_tf.pcd", "screwdriver_ascii.pcd", "screwdriver_ascii_tf.pcd",
-               "eraser_ascii.pcd"):
+               "eraser_ascii.pcd", "eraser_ascii_tf.pcd", "clamp_ascii.pcd", "clamp_ascii_tf.pcd"):
         shutil.copyfile(os.path.join(odir, fn), os.path.join(HERE, fn))
     txt = open(os.path.join(odir, "transforms.txt")).read()
     out = {}

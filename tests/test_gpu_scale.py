@@ -121,12 +121,20 @@ def test_every_icp_driver_gives_the_same_bits(O, template, mode, monkeypatch):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("which", ["generated_10700", "reference_21400"])
 @pytest.mark.parametrize("mode", ["sliced", "cluster", "pipe"])
-def test_template_larger_than_lds_in_batch_mode(O, mode, monkeypatch):
-    """A 10 700-point template does not fit the LDS image: the whole-cluster drivers fall back to the chunked
-    search of k_icp_cluster ('pipe' must notice and do the same); results still match the oracle bit for bit."""
+def test_template_larger_than_lds_in_batch_mode(O, mode, which, monkeypatch):
+    """A 10 700-point template - and the reference's own 21 400-point six-face template_cuboid_L200_W100_H75.pcd - do not
+    fit the LDS image: the whole-cluster drivers fall back to the chunked search of k_icp_cluster ('pipe' must notice
+    and do the same); results still match the oracle bit for bit."""
+    from conftest import GOLDEN
+    from perception_amd import pcd
     monkeypatch.setenv("CUBOID_ICP_MODE", mode)
-    big = templates.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)
+    if which == "generated_10700":
+        big = templates.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)
+    else:
+        big = pcd.read_xyz(os.path.join(GOLDEN, "template_cuboid_L200_W100_H75.pcd")).astype(np.float32)
+        assert len(big) == 21400
     assert len(big) > 7616
     frames = np.stack([synth.frame(i) for i in (0, 5)], 0)
     prm = capi.default_params()
