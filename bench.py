@@ -37,16 +37,18 @@ def _render(i):
     return synth.frame(i)
 
 
-def make_frames(start, count):
+def make_frames(start, count, config=3):
     """Synthetic frames [start, start+count), rendered on host threads (numpy releases the
     GIL in its array loops).  No fork/exec: under rocprofv3 the GPU runtime is already
     initialised when this runs, and forking such a process hangs."""
     from concurrent.futures import ThreadPoolExecutor
+    from perception_amd import synth
     nthr = max(1, min(16, (os.cpu_count() or 2), count))
-    out = np.empty((count, 640 * 480, 4), np.float32)
+    npts = synth.CONFIG5_SENSOR ** 2 if config == 5 else 640 * 480
+    out = np.empty((count, npts, 4), np.float32)
 
     def work(i):
-        out[i] = _render(start + i)
+        out[i] = synth.frame_config5(start + i) if config == 5 else _render(start + i)
 
     with ThreadPoolExecutor(nthr) as ex:
         list(ex.map(work, range(count)))
@@ -188,7 +190,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to use, one rank process per GPU (default: WORLD_SIZE or 1)")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300, about 2.5 s of timed region)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=256, help="frames per GPU per step (BASELINE config 3: 256)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (BASELINE config 3: 256; config 5: 8)")
+    ap.add_argument("--config", type=int, default=3, choices=(3, 5),
+                    help="3: the headline workload (256 D435 frames per GPU, one template); 5: the multi-template stress of "
+                         "BASELINE config 5 (1 M-point frames, five cuboids, five templates, every cluster x every template)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency measurement (BASELINE config 2; runs after the timed region)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed path's records (runs after the timed region)")
@@ -199,8 +204,10 @@ def main():
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial)")
     args = ap.parse_args()
+    if args.frames is None:
+        args.frames = 256 if args.config == 3 else 8
     if args.steps is None:
-        args.steps = 300
+        args.steps = 300 if args.config == 3 else 40
     if args.steps < 1 or args.warmup < 0 or args.frames < 1:
         raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 
@@ -217,7 +224,7 @@ def main():
         return dry_run(rank, local_rank, world)
 
     # host-side inputs first (fork pool must not follow GPU init)
-    frames = make_frames(rank * F, F)
+    frames = make_frames(rank * F, F, args.config)
 
     import torch
     import torch.distributed as dist
@@ -241,9 +248,16 @@ def main():
     tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
     prm = capi.default_params()
     prm.rgb_offset = 12
+    tpl_by_slot = {0: tpl}
+    if args.config == 5:
+        from perception_amd import synth
+        tpl_by_slot = {k: templates.template_xyz32(L, W, H, d) for k, (L, W, H, d) in enumerate(synth.CONFIG5_DIMS)}
+        prm.template_slot = -1
+        prm.crop_x_min, prm.crop_x_max = -synth.CONFIG5_CROP_X, synth.CONFIG5_CROP_X
+        prm.crop_z_max = prm.crop2_z_max = 1.2
     N = frames.shape[1]
     M = max(1, args.inflight)
-    pipe = batch.BatchPipeline(N, F, {0: tpl}, device_id=local_rank, inflight=M)
+    pipe = batch.BatchPipeline(N, F, tpl_by_slot, device_id=local_rank, inflight=M)
     ctx = pipe.contexts[0]
     d_frames = torch.from_numpy(frames).to(dev)           # resident in HBM before timing
     torch.cuda.synchronize()
@@ -359,7 +373,10 @@ def main():
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": ("batch of %d synthetic 640x480 D435 frames per GPU (BASELINE config 3), cuboid launch "
+            "config": {"workload": ("batch of %d synthetic 1 M-point frames per GPU (BASELINE config 5: 1000x1000 virtual sensor, five "
+                                    "cuboids, five templates %s, every cluster against every template, lowest fitness wins)"
+                                    % (F, [len(t) for t in tpl_by_slot.values()])) if args.config == 5 else
+                                   ("batch of %d synthetic 640x480 D435 frames per GPU (BASELINE config 3), cuboid launch "
                                     "parameters, 7250-point template, full chain S0-S6 + pose-record gather" % F) if world == 1 else
                                    ("batch of %d synthetic 640x480 D435 frames sharded frame-per-GPU over %d GPUs, %d per GPU "
                                     "(BASELINE config 4%s), RCCL all_gather of the pose records per batch; per GPU the config-3 "
@@ -396,7 +413,7 @@ def main():
             "icp": {"clusters": ncl, "accepted": int(acc), "mean_iterations": float(np.mean(iters)) if iters else 0.0,
                     "max_iterations": int(max(iters)) if iters else 0, "frames": nfr},
         }
-        if not args.no_cpu_baseline and world == 1:   # the contract: rank 0 at N=1 only
+        if not args.no_cpu_baseline and world == 1 and args.config == 3:   # the contract: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(frames, prm, tpl, gpu_records=allrec)
             out["speedup_vs_cpu_1thread"] = value / out["cpu_baseline"]["value"]
         print(json.dumps(out))

@@ -100,6 +100,34 @@ def scene_grid(index, cols=4, rows=3, dims=(0.05, 0.05, 0.03), pitch=(0.085, 0.0
     return sc
 
 
+# BASELINE config 5: five cuboids of distinct dimensions = the five templates: the three dims the reference
+# ships templates for + 150x150x50 + 100x100x100 mm; (L, W, H, d = template grid pitch)
+CONFIG5_DIMS = ((0.2, 0.1, 0.03, 0.002), (0.2, 0.075, 0.1, 0.005), (0.2, 0.1, 0.075, 0.005), (0.15, 0.15, 0.05, 0.002), (0.1, 0.1, 0.1, 0.002))
+CONFIG5_CROP_X = 0.5      # crops widened to the table
+CONFIG5_SENSOR = 1000     # 1000 x 1000 virtual sensor = 1 M points per frame
+
+
+def scene_config5(index):
+    """Frame `index` of the config-5 stress: the table with one cuboid of each of CONFIG5_DIMS."""
+    sc = scene_for(index, k_obj=0)
+    u = _uniform(sc["seed"], 13, 16)
+    n, e1, e2, p0 = sc["n"], sc["e1"], sc["e2"], sc["p0"]
+    spots = ((-0.26, -0.08), (0.0, -0.10), (0.27, -0.07), (-0.15, 0.17), (0.16, 0.18))
+    boxes = []
+    for k, ((a, b), (L, W, H, _)) in enumerate(zip(spots, CONFIG5_DIMS)):
+        yaw = np.deg2rad(30.0 * (u[3 * k] - 0.5))
+        ex = np.cos(yaw) * e1 + np.sin(yaw) * e2
+        ey = np.cross(n, ex)
+        ctr = p0 + (a + 0.02 * (u[3 * k + 1] - 0.5)) * e1 + (b + 0.02 * (u[3 * k + 2] - 0.5)) * e2 + (H / 2.0) * n
+        boxes.append(dict(R=np.stack([ex, ey, n], axis=1), c=ctr, half=np.array([L, W, H]) / 2.0, yaw=yaw))
+    sc["boxes"] = boxes
+    return sc
+
+
+def frame_config5(index):
+    return render(scene_config5(index), width=CONFIG5_SENSOR, height=CONFIG5_SENSOR)
+
+
 _RAY_CACHE = {}
 
 

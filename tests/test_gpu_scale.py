@@ -264,3 +264,51 @@ def test_template_arena_is_reclaimed(O, template):
         assert e.value.status == capi.CD_ERR_CAPACITY
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_config5_one_million_points_five_templates(O):
+    """BASELINE config 5 as SURVEY 8(d) writes it: a 1 M-point frame (1000 x 1000 virtual sensor), five cuboids of distinct
+    dimensions, five templates - the three the reference ships dims for (one of them the committed 1700-point file with its
+    origin at a corner), 150x150x50 (9375 points: does NOT fit the LDS image) and 100x100x100 at d = 0.002 - crops widened
+    to the table, template_slot = -1: every cluster against every template, the lowest fitness wins."""
+    from conftest import GOLDEN
+    from perception_amd import pcd
+    frame = synth.frame_config5(0)
+    assert frame.shape == (1000000, 4)
+    tpls = []
+    for k, (L, W, H, d) in enumerate(synth.CONFIG5_DIMS):
+        if k == 2:
+            tpls.append(pcd.read_xyz(os.path.join(GOLDEN, "template_cuboid_L200_W100_H75_3faces.pcd")).astype(np.float32))
+        else:
+            tpls.append(templates.template_xyz32(L, W, H, d))
+    assert [len(t) for t in tpls] == [7250, 1700, 1700, 9375, 7500]
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    prm.crop_x_min, prm.crop_x_max = -synth.CONFIG5_CROP_X, synth.CONFIG5_CROP_X
+    prm.crop_z_max = prm.crop2_z_max = 1.2
+    per = []
+    for slot, t in enumerate(tpls):
+        prm.template_slot = slot
+        per.append(O.process_frame(frame, prm, t, all_clusters=16))
+    assert per[0]["result"].n_clusters == 5
+    ctx = capi.Context(max_points=frame.shape[0], max_frames=1)
+    try:
+        for slot, t in enumerate(tpls):
+            ctx.set_template(slot, t)
+        prm.template_slot = -1
+        res, pi, lb = ctx.process_batch(frame[None], prm, want_indices=True)
+        r, ro = res[0], per[0]["result"]
+        assert (r.n_cropped, r.n_voxels, r.n_plane, r.n_objects, r.n_clusters) == (ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters)
+        assert np.array_equal(pi[0][:r.n_plane], per[0]["plane_inliers"]) and np.array_equal(lb[0][:r.n_objects], per[0]["labels"])
+        picked = []
+        for k in range(r.n_clusters):
+            want = min(range(5), key=lambda s_: (per[s_]["clusters"][k].fitness, s_))
+            a, b = r.clusters[k], per[want]["clusters"][k]
+            assert a.template_slot == want, k
+            assert (a.size, a.iterations, a.converged, a.accepted) == (b.size, b.iterations, b.converged, b.accepted), k
+            assert list(a.T) == list(b.T) and a.fitness == b.fitness, k
+            picked.append(want)
+        assert len(set(picked)) >= 3      # the templates really compete: different cuboids pick different templates
+    finally:
+        ctx.close()
