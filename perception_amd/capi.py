@@ -23,7 +23,7 @@ CD_ERR_FEW_CORRESPONDENCES = -5
 CD_ERR_LEAF_TOO_SMALL = -6
 CD_ERR_NO_TEMPLATE = -7
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcuboid_hip.so")
+LIB_PATH = os.environ.get("CUBOID_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libcuboid_hip.so")
 
 # every symbol include/cuboid_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
