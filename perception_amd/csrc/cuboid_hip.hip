@@ -186,10 +186,11 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     int max_nc = 0, max_bits = 0;
     for (int f = 0; f < F; ++f) { max_nc = std::max(max_nc, c->h_fs[f].n_c); max_bits = std::max(max_bits, c->h_fs[f].key_bits); }
     const int Tc = std::max(1, (max_nc + TILE - 1) / TILE);
+    const int Ts = (c->N + SORT_TILE - 1) / SORT_TILE, Tsc = std::max(1, (max_nc + SORT_TILE - 1) / SORT_TILE);
     int cur = 0;
     const uint32_t* vin = nullptr;
     for (int shift = 0; shift < max_bits; shift += RADIX_BITS) {
-        LAUNCH(c, launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, T, Tc, shift, c->d_fs, c->d_hist));
+        LAUNCH(c, launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, Ts, Tsc, shift, c->d_fs, c->d_hist));
         cur ^= 1;
         vin = c->d_val[cur];
     }
@@ -774,7 +775,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_cpt, FN) == hipSuccess && dalloc(&c->d_vox, FN) == hipSuccess && dalloc(&c->d_obj, FN) == hipSuccess;
     ok = ok && dalloc(&c->d_src0, FN) == hipSuccess && dalloc(&c->d_src, FN) == hipSuccess;
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
-    ok = ok && dalloc(&c->d_hist, F * RADIX * T) == hipSuccess;
+    ok = ok && dalloc(&c->d_hist, F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
     ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess && halloc(&c->h_models, F * MAX_HYP) == hipSuccess;

@@ -3,33 +3,38 @@
 // VoxelGrid sorts the cropped points by voxel index (pcl::VoxelGrid::applyFilter uses
 // std::sort on (idx, point) pairs; rule C2 makes it stable).  One pass = three kernels over
 // ordered tiles of 2048 pairs:
-//   hist    : per-tile digit histogram (LDS atomics)            -> hist[f][digit][tile]
+//   hist    : per-tile digit histogram (LDS atomics)            -> hist[f][tile][digit]  (digit fastest: every
+//             access of the three kernels to it is coalesced)
 //   scan    : per frame, exclusive scan in (digit, tile) order  -> global base of every bin
 //   scatter : stable rank of each pair inside its tile with wave ballots ("match-any" over
 //             the 8 digit bits, 64-wide), then one scattered store per pair.
 // Element order inside a tile is (wave, row, lane), so per-wave running bin counts kept in
-// LDS plus a cross-wave prefix give the stable position.
+// LDS plus a cross-wave prefix give the stable position.  A sort tile is 8192 pairs (1024 threads x 8 rows): with 256
+// bins a tile sends ~32 consecutive pairs to each bin, so the scattered 4-byte stores fill whole 128-byte lines (with
+// 2048-pair tiles the scatter wrote twice the bytes it stored).
 #include "kernels.hpp"
 
 namespace cd {
 
-__global__ void __launch_bounds__(BLOCK) k_radix_hist(const uint32_t* __restrict__ kin, int N, int T, int shift,
-                                                      const FrameState* __restrict__ fs, uint32_t* __restrict__ hist) {
+constexpr int SORT_WAVES = SORT_BLOCK / WAVE;
+
+__global__ void __launch_bounds__(SORT_BLOCK) k_radix_hist(const uint32_t* __restrict__ kin, int N, int T, int shift,
+                                                           const FrameState* __restrict__ fs, uint32_t* __restrict__ hist) {
     __shared__ uint32_t s_h[RADIX];
     const int f = blockIdx.y, tile = blockIdx.x;
     const int n = fs[f].n_c;
-    if (tile * TILE >= n) return;
-    s_h[threadIdx.x] = 0;
+    if (tile * SORT_TILE >= n) return;
+    if (threadIdx.x < RADIX) s_h[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t* k = kin + (size_t)f * N;
-    const int base = tile * TILE + (threadIdx.x >> 6) * WAVE_SPAN + (threadIdx.x & 63);
+    const int base = tile * SORT_TILE + (threadIdx.x >> 6) * WAVE_SPAN + (threadIdx.x & 63);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         if (e < n) atomicAdd(&s_h[(k[e] >> shift) & (RADIX - 1)], 1u);
     }
     __syncthreads();
-    hist[((size_t)f * RADIX + threadIdx.x) * T + tile] = s_h[threadIdx.x];
+    if (threadIdx.x < RADIX) hist[((size_t)f * T + tile) * RADIX + threadIdx.x] = s_h[threadIdx.x];
 }
 
 // one block per frame; thread d owns digit d's row of Tact tiles
@@ -38,12 +43,12 @@ __global__ void __launch_bounds__(BLOCK) k_radix_scan(int T, const FrameState* _
     const int f = blockIdx.x, d = threadIdx.x, w = d >> 6, lane = d & 63;
     const int n = fs[f].n_c;
     if (n <= 0) return;
-    const int tact = (n + TILE - 1) / TILE;
-    uint32_t* row = hist + ((size_t)f * RADIX + d) * T;
+    const int tact = (n + SORT_TILE - 1) / SORT_TILE;
+    uint32_t* col = hist + (size_t)f * T * RADIX + d;
     uint32_t sum = 0;
     for (int t = 0; t < tact; ++t) {
-        const uint32_t v = row[t];
-        row[t] = sum;
+        const uint32_t v = col[(size_t)t * RADIX];
+        col[(size_t)t * RADIX] = sum;
         sum += v;
     }
     uint32_t inc = sum;
@@ -56,24 +61,23 @@ __global__ void __launch_bounds__(BLOCK) k_radix_scan(int T, const FrameState* _
     __syncthreads();
     uint32_t base = inc - sum;
     for (int q = 0; q < w; ++q) base += s_w[q];
-    for (int t = 0; t < tact; ++t) row[t] += base;
+    for (int t = 0; t < tact; ++t) col[(size_t)t * RADIX] += base;
 }
 
-__global__ void __launch_bounds__(BLOCK) k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
+__global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
                                                          int T, int shift, const FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_wh[WAVES_PER_BLOCK][RADIX];
+    __shared__ uint32_t s_wh[SORT_WAVES][RADIX];
     __shared__ uint32_t s_goff[RADIX];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
-    if (tile * TILE >= n) return;
+    if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
-#pragma unroll
-    for (int q = 0; q < WAVES_PER_BLOCK; ++q) s_wh[q][threadIdx.x] = 0;
-    s_goff[threadIdx.x] = hist[((size_t)f * RADIX + threadIdx.x) * T + tile];
+    for (int q = threadIdx.x; q < SORT_WAVES * RADIX; q += SORT_BLOCK) (&s_wh[0][0])[q] = 0;
+    if (threadIdx.x < RADIX) s_goff[threadIdx.x] = hist[((size_t)f * T + tile) * RADIX + threadIdx.x];
     __syncthreads();
-    const int base = tile * TILE + w * WAVE_SPAN + lane;
+    const int base = tile * SORT_TILE + w * WAVE_SPAN + lane;
     const uint64_t lt = lanemask_lt();
     uint32_t key[ITEMS], rank[ITEMS];
 #pragma unroll
@@ -99,11 +103,11 @@ __global__ void __launch_bounds__(BLOCK) k_radix_scatter(const uint32_t* __restr
         rank[j] = bin_base + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    {   // per-digit exclusive prefix over the 4 waves
+    if (threadIdx.x < RADIX) {   // per-digit exclusive prefix over the waves
         const int d = threadIdx.x;
         uint32_t run = 0;
 #pragma unroll
-        for (int q = 0; q < WAVES_PER_BLOCK; ++q) {
+        for (int q = 0; q < SORT_WAVES; ++q) {
             const uint32_t c = s_wh[q][d];
             s_wh[q][d] = run;
             run += c;
@@ -122,11 +126,12 @@ __global__ void __launch_bounds__(BLOCK) k_radix_scatter(const uint32_t* __restr
     }
 }
 
+// T = sort tiles per frame the histogram is laid out for, Tact = sort tiles that hold data (max over the frames)
 void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
                        int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(Tact, F), dim3(BLOCK), 0, s, kin, N, T, shift, fs, hist);
+    hipLaunchKernelGGL(k_radix_hist, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, N, T, shift, fs, hist);
     hipLaunchKernelGGL(k_radix_scan, dim3(F), dim3(BLOCK), 0, s, T, fs, hist);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(Tact, F), dim3(BLOCK), 0, s, kin, vin, kout, vout, N, T, shift, fs, hist);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, N, T, shift, fs, hist);
 }
 
 }  // namespace cd
