@@ -29,7 +29,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak
-PMC_TRAFFIC_FILE = "r01_pmc_traffic.json"   # HBM bytes per dispatch from the separate --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # HBM bytes per dispatch from the separate --pmc FETCH_SIZE / WRITE_SIZE passes
 
 
 def _render(i):
