@@ -386,9 +386,11 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
     // The pipelined variant (two clusters in flight per workgroup, no barrier in the iteration loop) needs one
     // LDS-resident gridded template shared by every cluster of the launch; otherwise k_icp_cluster runs.
-    const bool whole_cluster = c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2);
     bool pipe_ok = c->icp_mode != 2 && c->h_cl[0].tpl_m > 0 && c->h_cl[0].tpl_m <= ICP_TPL_LDS && c->tpl_gridded[c->h_cl[0].slot];
     for (int k = 1; k < ncl && pipe_ok; ++k) pipe_ok = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
+    // (auto mode: only the pipelined kernel beats the sliced driver; with mixed or non-resident templates k_icp_cluster's
+    // barrier per iteration costs more than it saves, so those batches stay sliced unless the mode is forced)
+    const bool whole_cluster = c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2 && pipe_ok);
     if (whole_cluster) {
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
@@ -612,7 +614,73 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     std::vector<cd_cluster_result>& best = c->last_clusters;
     best.assign((size_t)std::max(ncl, 1), cd_cluster_result());
     long long pairs = 0;
-    for (size_t si = 0; si < slots.size(); ++si) {
+    // Several templates: when S copies of every frame's ICP sources fit its segment of the source buffers (they do unless a
+    // frame is nearly all objects), every (cluster, template) pair becomes one ICP problem of ONE stage - the batch then
+    // fills the chip with S x ncl problems instead of running S under-filled passes one after the other.
+    const int S = (int)slots.size();
+    bool one_stage = S > 1 && ncl > 0;
+    std::vector<int> span((size_t)F, 0);
+    for (int f = 0; f < F; ++f) {
+        for (int k = first_cl[(size_t)f]; k < first_cl[(size_t)f + 1]; ++k) span[(size_t)f] += csize[(size_t)k];
+        if ((long long)S * span[(size_t)f] > (long long)c->N) one_stage = false;
+    }
+    if ((long long)S * ncl > 0x3fffffffll) one_stage = false;
+    if (one_stage) {
+        const size_t need = (size_t)S * rounds_k * F * KICP;   // source offsets of copy t, round r: [t][r][F][KICP]
+        if (need > c->koffx_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_koffx) hipFree(c->d_koffx);
+            c->d_koffx = nullptr; c->koffx_cap = 0;
+            HIPCHK(c, dalloc(&c->d_koffx, need));
+            c->koffx_cap = need;
+        }
+        std::vector<int> tab(need, 0);
+        for (int t = 0; t < S; ++t)
+            for (int r = 0; r < rounds_k; ++r)
+                for (int f = 0; f < F; ++f)
+                    for (int k = 0; k < KICP; ++k) {
+                        const int q = first_cl[(size_t)f] + r * KICP + k;
+                        if (q < first_cl[(size_t)f + 1]) tab[(((size_t)t * rounds_k + r) * F + f) * KICP + k] = coff[(size_t)q] + t * span[(size_t)f];
+                    }
+        HIPCHK(c, copy_sync(c, c->d_koffx, tab.data(), sizeof(int) * need, hipMemcpyHostToDevice));
+        for (int t = 0; t < S; ++t)
+            for (int r = 0; r < rounds_k; ++r) {
+                if (rounds_k > 1) {   // with a single round the tile counts of stage_cluster are still in d_tileK
+                    HIPCHK(c, hipMemsetAsync(c->d_tileK, 0, sizeof(int) * (size_t)F * KICP * c->T, c->stream));
+                    LAUNCH(c, launch_label_count(c->stream, c->N, F, c->T, To2, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK, r * KICP));
+                    LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileK, F * KICP, c->T, nullptr, 0));
+                }
+                LAUNCH(c, launch_label_scatter(c->stream, c->d_obj, c->N, F, c->T, To2, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src, r * KICP,
+                                               c->d_koffx + (((size_t)t * rounds_k + r) * F) * KICP));
+            }
+        st = ensure_clusters(c, S * ncl, (long long)S * cl_points);
+        if (st) return st;
+        for (int t = 0; t < S; ++t) {
+            int q = 0;
+            for (int f = 0; f < F; ++f)
+                for (int k = 0; k < c->h_fs[f].n_k; ++k, ++q) {
+                    IcpCluster& cl = c->h_cl[(size_t)t * ncl + q];
+                    cl.src_off = f * c->N + coff[(size_t)q] + t * span[(size_t)f];
+                    cl.n = csize[(size_t)q];
+                    cl.frame = f;
+                    cl.k = k;
+                    cl.tpl_off = c->tpl_off[slots[(size_t)t]];
+                    cl.tpl_m = c->tpl_m[slots[(size_t)t]];
+                    cl.tile0 = 0;
+                    cl.slot = slots[(size_t)t];
+                }
+        }
+        st = stage_icp(c, S * ncl, p, &pairs);
+        if (st) return st;
+        for (int t = 0; t < S; ++t)
+            for (int k = 0; k < ncl; ++k) {
+                cd_cluster_result r;
+                fill_cluster_result(c, t * ncl + k, p, &r);
+                r.template_slot = slots[(size_t)t];
+                if (t == 0 || r.fitness < best[(size_t)k].fitness) best[(size_t)k] = r;
+            }
+    }
+    for (size_t si = 0; si < slots.size() && !one_stage; ++si) {
         const int slot = slots[si];
         st = extract_sources(si > 0);
         if (st) return st;
