@@ -90,3 +90,45 @@ def test_batch_with_mixed_cluster_counts_and_two_templates(O, small_tpl, templat
         assert res[0].flags == capi.CD_FRAME_MORE_CLUSTERS and res[1].flags == 0
     finally:
         ctx.close()
+
+
+def test_two_templates_when_the_source_copies_do_not_fit(O, small_tpl, template):
+    """template_slot = -1 normally gives every template its own copy of a frame's ICP sources and runs all (cluster, template)
+    pairs as one stage; a frame that is mostly objects has no room for the copies (S x sources > points per frame) and falls
+    back to one pass per template.  Same answers either way."""
+    rng = np.random.default_rng(12)
+    plane = np.c_[rng.uniform(-0.19, 0.19, (1500, 2)), np.full(1500, 0.6)]
+    boxes = []
+    for cx in (-0.12, 0.0, 0.12):      # three dense balls well above the plane: over half of all points
+        d = rng.normal(size=(1400, 3))
+        d *= (0.04 * rng.uniform(0, 1, (1400, 1)) ** (1 / 3)) / np.linalg.norm(d, axis=1, keepdims=True)
+        boxes.append(d + [cx, 0.0, 0.5])
+    cloud = np.concatenate([plane] + boxes).astype(np.float32)
+    cloud = np.c_[cloud, np.zeros(len(cloud), np.float32)]
+    prm = capi.default_params()
+    prm.leaf_size = 0.002
+    prm.plane_distance_threshold = 0.01
+    prm.cluster_min_size = 100
+    prm.icp_max_iterations = 30
+    per = {}
+    for s_, tp in ((0, small_tpl), (1, template)):
+        prm.template_slot = s_
+        per[s_] = O.process_frame(cloud, prm, tp, all_clusters=16)
+    ro = per[0]["result"]
+    assert ro.n_clusters >= 3 and 2 * sum(c.size for c in per[0]["clusters"]) > len(cloud)      # the copies of two templates cannot fit
+    ctx = capi.Context(max_points=len(cloud), max_frames=1)
+    try:
+        ctx.set_template(0, small_tpl)
+        ctx.set_template(1, template)
+        prm.template_slot = -1
+        res, _, lb = ctx.process_batch(cloud[None], prm, want_indices=True)
+        assert res[0].n_clusters == ro.n_clusters and np.array_equal(lb[0][:ro.n_objects], per[0]["labels"])
+        got = ctx.cluster_results(0)
+        for k in range(ro.n_clusters):
+            want = min((0, 1), key=lambda s_: (per[s_]["clusters"][k].fitness, s_))
+            g, w = got[k], per[want]["clusters"][k]
+            assert g.template_slot == want
+            assert (g.size, g.iterations, g.converged) == (w.size, w.iterations, w.converged)
+            assert list(g.T) == list(w.T) and g.fitness == w.fitness
+    finally:
+        ctx.close()

@@ -35,7 +35,7 @@ def run(mode):
     return rec, ts
 
 
-rec, ts = run(None)
+rec, ts = run(os.environ.get("CUBOID_ICP_MODE"))   # None: the library's own choice
 icp = [t[0] for t in ts[1:]] or [ts[0][0]]
 st = np.array([t[1] for t in ts[1:]] or [ts[0][1]])
 print("icp_kernel_ms min %.3f avg %.3f | stages crop_voxel %.3f plane %.3f extract_cluster %.3f icp %.3f total %.3f" %
