@@ -80,7 +80,11 @@ struct IcpGrid {
     int32_t nx, ny, nz;
     int32_t ncell;         // 0: no table (template does not fit LDS)
     int32_t cell_off;      // offset of this template's start table in the table buffer
-    int32_t pad[2];
+    // k-d patch layout: the first kd_split patches are the left half of the root split, the others the right half; the
+    // tight boxes of the two halves let the wave-per-query search skip the box tests of a half a query cannot reach
+    int32_t kd_split;
+    int32_t pad;
+    float half_lo[2][4], half_hi[2][4];
 };
 
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity

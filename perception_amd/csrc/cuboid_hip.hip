@@ -1044,6 +1044,26 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
         }
     }
     layout(P->kd_pts, P->kd_lo, P->kd_hi);
+    {   // the two halves of the root split (the stack above splits [0, m) at k0 first; patches are whole on either side)
+        int k0 = m;
+        if (m > ICP_SUB) {
+            k0 = ((m / 2 + ICP_SUB - 1) / ICP_SUB) * ICP_SUB;
+            if (k0 >= m) k0 -= ICP_SUB;
+        }
+        grid.kd_split = k0 >= m ? m_pad / ICP_SUB : k0 / ICP_SUB;
+        const int nrun = m_pad / ICP_SUB;
+        for (int h = 0; h < 2; ++h) {
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            const int r0 = h == 0 ? 0 : grid.kd_split, r1 = h == 0 ? grid.kd_split : nrun;
+            for (int r = r0; r < r1; ++r) {
+                const float lo3[3] = {P->kd_lo[(size_t)r].x, P->kd_lo[(size_t)r].y, P->kd_lo[(size_t)r].z};
+                const float hi3[3] = {P->kd_hi[(size_t)r].x, P->kd_hi[(size_t)r].y, P->kd_hi[(size_t)r].z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], lo3[a]); mx[a] = std::fmax(mx[a], hi3[a]); }
+            }
+            for (int a = 0; a < 3; ++a) { grid.half_lo[h][a] = mn[a]; grid.half_hi[h][a] = mx[a]; }   // an empty half keeps +-FLT_MAX: never reached
+            grid.half_lo[h][3] = grid.half_hi[h][3] = 0.f;
+        }
+    }
     if (m <= ICP_TPL_LDS) {
         // k-d patch r = the cell-sorted positions kdmap[64 r .. 64 r + 63]: the pipelined kernel searches far queries
         // patch by patch THROUGH this table (compact boxes) while the points themselves stay cell-sorted in LDS

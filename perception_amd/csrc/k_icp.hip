@@ -330,22 +330,22 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
 // for every point p filed in the row).  A point that can still beat or tie the seed has real
 // dx^2 <= bound*(1+5u) - (dy^2+dz^2) <= rem := rr2 - e2*(1-1e-6); rem < 0 skips the row, otherwise the x-range
 // shrinks to the cells of q_x -+ sqrt(rem).
+// The point loop has no divergent branch: a lane without a point to test reads the +inf pad point `pad`, whose key can never
+// win.  (A select-only version of the row step was measured too: same time, so the row step keeps its early-outs.)
 __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
-                                            QueryRegs& q) {
-    float lbest = q.pbest;
-    int lbi = q.pbi, loi = 0x7fffffff;
-    int y0 = 0, y1 = 0, z1 = -1, ry = 0, rz = 0;
-    float slx = 0.f, sly = 0.f, slz = 0.f, rr2 = 0.f;
-    if (act) {
-        slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
-        sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
-        slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
-        const float ryy = __fadd_rn(rr, sly), rzz = __fadd_rn(rr, slz);
-        y0 = grid_coord(__fsub_rn(q.py, ryy), g.oy, g.inv, g.ny); y1 = grid_coord(__fadd_rn(q.py, ryy), g.oy, g.inv, g.ny);
-        rz = grid_coord(__fsub_rn(q.pz, rzz), g.oz, g.inv, g.nz); z1 = grid_coord(__fadd_rn(q.pz, rzz), g.oz, g.inv, g.nz);
-        ry = y0;
-        rr2 = __fmul_rn(__fmul_rn(rr, rr), 1.0f + 1.0e-6f);
-    }
+                                            QueryRegs& q, int pad) {
+    // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
+    // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it)
+    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
+    int lbi = q.pbi;
+    const float slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
+    const float sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
+    const float slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
+    const float ryy = __fadd_rn(rr, sly), rzz = __fadd_rn(rr, slz);
+    const int y0 = grid_coord(__fsub_rn(q.py, ryy), g.oy, g.inv, g.ny), y1 = grid_coord(__fadd_rn(q.py, ryy), g.oy, g.inv, g.ny);
+    const int z1 = grid_coord(__fadd_rn(q.pz, rzz), g.oz, g.inv, g.nz);
+    int ry = y0, rz = grid_coord(__fsub_rn(q.pz, rzz), g.oz, g.inv, g.nz);
+    const float rr2 = __fmul_rn(__fmul_rn(rr, rr), 1.0f + 1.0e-6f);
     const float huge = 3.0e38f;
     int i = 0, b = 0;
     bool more = act;
@@ -382,28 +382,29 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
             }
         }
         if (!__ballot(more)) break;
-        // B: test the points of the current ranges
+        // B: test the points of the current ranges, two per trip
         while (__ballot(more && i < b)) {
 #ifdef CD_STATS
             { const unsigned long long pb_ = __ballot(more && i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
 #endif
-            if (more && i < b) {
-                // two points per trip (the second one is the first again when the range ends: a no-op for the update)
-                const int i1 = i + 1 < b ? i + 1 : i;
-                const float4 t = s_tpl[i];
-                const float4 u = s_tpl[i1];
-                const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
-                const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
-                const int o = __float_as_int(t.w), o1 = __float_as_int(u.w);
-                const bool up = (d < lbest) || (d == lbest && o < loi);
-                lbest = up ? d : lbest; lbi = up ? i : lbi; loi = up ? o : loi;
-                const bool up1 = (e < lbest) || (e == lbest && o1 < loi);
-                lbest = up1 ? e : lbest; lbi = up1 ? i1 : lbi; loi = up1 ? o1 : loi;
-                i += 2;
-            }
+            const bool on = more && i < b;
+            const int i0 = on ? i : pad;
+            const int i1 = (on && i + 1 < b) ? i + 1 : pad;
+            const float4 t = s_tpl[i0];
+            const float4 u = s_tpl[i1];
+            const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+            const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
+            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
+            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned)__float_as_int(u.w);
+            const bool up = kd_ < lkey;
+            lkey = up ? kd_ : lkey; lbi = up ? i0 : lbi;
+            const bool up1 = ke_ < lkey;
+            lkey = up1 ? ke_ : lkey; lbi = up1 ? i1 : lbi;
+            i = on ? i + 2 : i;
         }
     }
-    if (act && loi != 0x7fffffff) { q.pbest = lbest; q.pbi = lbi; q.poi = loi; }
+    const int loi = (int)(unsigned)(lkey & 0xffffffffull);
+    if (act && loi != 0x7fffffff) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = lbi; q.poi = loi; }
 }
 
 // Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
@@ -481,84 +482,93 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
     }
 }
 
-// search_chunk over k-d PATCHES of a cell-sorted template: run r = the 64 stored positions s_kd[64 r ..], its box in bx.
-// The points stay where the grid walk wants them; the wave-per-query search gets the compact boxes it wants.
+// Wave-per-query search over k-d PATCHES of a cell-sorted template: patch r = the 64 stored positions s_kd[64 r ..], its box
+// in bx.  The points stay where the grid walk wants them; this search gets the compact boxes it wants.  Lane l keeps the box
+// of patch l of the LEFT half of the k-d root split and of patch l of the RIGHT half (psplit = patches in the left half);
+// `need` says per query which halves its bound reaches at all (bit 0 / 1), so most queries test one box per lane, not two.
+//
+// Cost probes on the bench batch (the search run twice: +3.7 ms of 6.4; only the patch visits twice: +1.5 ms; only the box tests
+// twice: +0.4 ms) showed where a far query's time goes: not into the arithmetic but into the control flow around it.  What
+// paid: the lexicographic update as ONE 64-bit unsigned compare (the compiler turned "d < best || (d == best && oi < boi)"
+// into two nested exec-mask regions with branches per patch), 6.4 -> 6.0 ms.  What did not: two queries interleaved per trip
+// (same time: the SGPR pressure of two mask/coordinate sets spills to VGPR lanes).
+struct FarQ { float x, y, z, best; unsigned long long m0, m1; unsigned long long lkey; int lbi; };   // lkey = (d2 bits : original index)
+
+__device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const QueryRegs& q, int need, int k) {
+    f.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+    f.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+    f.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+    f.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+    const int nd = __builtin_amdgcn_readlane(need, k);
+    f.m0 = 0ull; f.m1 = 0ull;
+    if (nd & 1) f.m0 = __ballot(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
+    if (nd & 2) f.m1 = __ballot(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
+    // lanes start from (bound, no index): a lane can only be selected if it beat the bound, and the seed point itself does
+    f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull; f.lbi = 0;
+}
+__device__ __forceinline__ int far_next_patch(FarQ& f, int psplit) {   // wave-uniform; f.m0 | f.m1 != 0
+    int r;
+    if (f.m0) { r = __ffsll((long long)f.m0) - 1; f.m0 &= f.m0 - 1; }
+    else { r = psplit + __ffsll((long long)f.m1) - 1; f.m1 &= f.m1 - 1; }
+    return r;
+}
+__device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
+    // lexicographic (d2, original index) minimum, rule C5, as ONE unsigned 64-bit compare: squared distances are non-negative
+    // floats (or +inf / NaN-free here), which order like their bit patterns; no branch, no tie special case
+    const float d = dist2(f.x, f.y, f.z, t.x, t.y, t.z);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
+    const bool up = key < f.lkey;
+    f.lkey = up ? key : f.lkey; f.lbi = up ? pos : f.lbi;
+}
+// lexicographic minimum over the wave.  Only lanes that beat the incoming bound can hold it; when exactly one did (the usual
+// case once seeds are tight) it IS the answer and three v_readlane replace the reduction.
+__device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k) {
+    const float lbest = __uint_as_float((unsigned)(f.lkey >> 32));
+    const int loi = (int)(unsigned)(f.lkey & 0xffffffffull);
+    const unsigned long long imp = __ballot(f.lkey < (((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull));
+    if (imp == 0) return;
+    float dmin;
+    int rbi, roi;
+    if (__popcll(imp) == 1) {
+        const int l = __ffsll((long long)imp) - 1;
+        dmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), l));
+        rbi = __builtin_amdgcn_readlane(f.lbi, l);
+        roi = __builtin_amdgcn_readlane(loi, l);
+    } else {
+        dmin = wave_min_f32_nonneg(lbest);
+        unsigned long long eq = __ballot(lbest == dmin);
+        rbi = 0; roi = 0x7fffffff;
+        while (eq) {
+            const int l = __ffsll((long long)eq) - 1;
+            eq &= eq - 1;
+            const int oi_ = __builtin_amdgcn_readlane(loi, l);
+            const int bi_ = __builtin_amdgcn_readlane(f.lbi, l);
+            if (oi_ <= roi) { roi = oi_; rbi = bi_; }
+        }
+    }
+    if ((int)(threadIdx.x & 63) == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
+}
+
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
-                                               unsigned long long todo, int* stat_acc = nullptr) {
-    const int c0 = 0;
+                                               unsigned long long todo, int psplit, int need, int* stat_acc = nullptr) {
     const int lane = threadIdx.x & 63;
-#ifdef CD_STATS
-    const int nruns = (cn + ICP_SUB - 1) / ICP_SUB;
-#endif
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
-        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
-        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
-        const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
-        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-        // Lanes start from (bound, no index): a lane can only be selected below if it beat `best`, and the
-        // seed point itself always does in the chunk that holds it.  Only when `best` is a real distance
-        // carried over from a lower chunk (c0 > 0) must ties against the carried neighbour be decided,
-        // so only then is its original index needed.
-        const int boi = c0 > 0 ? __builtin_amdgcn_readlane(q.poi, k) : 0x7fffffff;
-        unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
-        unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
+        FarQ A;
+        far_begin(A, bx, q, need, k);
 #ifdef CD_STATS
-        if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
+        if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(A.m0) + __popcll(A.m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
 #ifdef CD_ITSTATS
-        if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += __popcll(m0) + __popcll(m1); }
+        if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += __popcll(A.m0) + __popcll(A.m1); }
 #endif
-        float lbest = best;
-        int lbi = 0, loi = boi;
-        // Visit the surviving runs (1.5 per query on average, so no unrolling/padding).  The template is stored
-        // re-tiled into compact 64-point patches, so candidates are NOT met in original-index
-        // order: the update is the lexicographic (d2, original index) comparison (rule C5).
-#define CD_TAKE(dd, tt, rr)                                                                     \
-        {                                                                                       \
-            const int oi_ = __float_as_int(tt.w);                                               \
-            const bool up_ = (dd < lbest) || (dd == lbest && oi_ < loi);                        \
-            lbest = up_ ? dd : lbest; lbi = up_ ? p0_ : lbi; loi = up_ ? oi_ : loi; \
+        while (A.m0 | A.m1) {
+            const int r = far_next_patch(A, psplit);
+            const int pos = s_kd[r * ICP_SUB + lane];
+            far_take(A, s_tpl[pos], pos);
         }
-#define CD_VISIT2(mask, base)                                                                   \
-        while (mask) {                                                                          \
-            const int r0 = (base) + __ffsll((long long)mask) - 1; mask &= mask - 1;             \
-            const int p0_ = s_kd[r0 * ICP_SUB + lane];                                          \
-            const float4 t0 = s_tpl[p0_];                                                       \
-            const float d0 = dist2(x, y, z, t0.x, t0.y, t0.z);                                  \
-            CD_TAKE(d0, t0, r0)                                                                 \
-        }
-        CD_VISIT2(m0, 0)
-        CD_VISIT2(m1, 64)
-#undef CD_VISIT2
-#undef CD_TAKE
-        // lexicographic (d2, original index) minimum over the wave.  Only lanes that beat the incoming
-        // bound can hold it; when exactly one did (the usual case once seeds are tight) it IS the answer
-        // and three v_readlane replace the reduction.  Otherwise: min distance by DPP, then the lowest
-        // original index among the lanes that hold it.
-        const unsigned long long imp = __ballot(lbest < best || (lbest == best && loi < boi));
-        if (imp == 0) continue;   // nothing in this chunk beats the carried neighbour (multi-chunk templates only)
-        float dmin;
-        int rbi, roi;
-        if (__popcll(imp) == 1) {
-            const int l = __ffsll((long long)imp) - 1;
-            dmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), l));
-            rbi = __builtin_amdgcn_readlane(lbi, l);
-            roi = __builtin_amdgcn_readlane(loi, l);
-        } else {
-            dmin = wave_min_f32_nonneg(lbest);
-            unsigned long long eq = __ballot(lbest == dmin);
-            rbi = 0; roi = 0x7fffffff;
-            while (eq) {
-                const int l = __ffsll((long long)eq) - 1;
-                eq &= eq - 1;
-                const int oi_ = __builtin_amdgcn_readlane(loi, l);
-                const int bi_ = __builtin_amdgcn_readlane(lbi, l);
-                if (oi_ <= roi) { roi = oi_; rbi = bi_; }
-            }
-        }
-        if (lane == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
+        far_end(A, q, k);
     }
 }
 
@@ -784,6 +794,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
         const IcpGrid g = grids[c.slot];
         const bool grid_ok = resident && g.ncell > 0;
         const float rmax = __fmul_rn(prm.grid_rc, g.cell);
+        const int gpad = (c.tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB;   // first point of the +inf pad run of the staged image
         if (resident && staged != c.tpl_off) {
             __syncthreads();
             if (grid_ok) for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
@@ -839,7 +850,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
                     CD_PHASE(1)
 #ifdef CD_STATS
                     { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
@@ -934,7 +945,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
@@ -1061,10 +1072,23 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     const float4* tp = tpl + c0.tpl_off;
     const int tpl_m = c0.tpl_m;
     const float rmax = __fmul_rn(prm.grid_rc, g.cell);
+    const int gpad = (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB;   // first point of the +inf pad run of the staged image
     RunBoxes bx;
     for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
     for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = kdmap[c0.tpl_off + i];
     stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
+    // lane l keeps the boxes of patch l of the LEFT half of the k-d root split and of patch l of the RIGHT half
+    const int psplit = g.kd_split;
+    {
+        const int nruns = (tpl_m + ICP_SUB - 1) / ICP_SUB;
+        const float inf = __uint_as_float(0x7f800000u);
+        const float4 none = make_float4(inf, inf, inf, 0.f);
+        const float4* blo = tlo + c0.tpl_off / ICP_SUB;
+        const float4* bhi = thi + c0.tpl_off / ICP_SUB;
+        bx.L0 = bx.H0 = bx.L1 = bx.H1 = none;
+        if (lane < psplit) { bx.L0 = blo[lane]; bx.H0 = bhi[lane]; }
+        if (psplit + lane < nruns) { bx.L1 = blo[psplit + lane]; bx.H1 = bhi[psplit + lane]; }
+    }
     if (threadIdx.x == 0) {
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             PipeSlot* sl = &s_slot[sidx];
@@ -1156,19 +1180,23 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q);
+                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
+                    // which halves of the template can hold a point within this lane's bound (all lanes at once)
+                    const float4 hl0 = make_float4(g.half_lo[0][0], g.half_lo[0][1], g.half_lo[0][2], 0.f), hh0 = make_float4(g.half_hi[0][0], g.half_hi[0][1], g.half_hi[0][2], 0.f);
+                    const float4 hl1 = make_float4(g.half_lo[1][0], g.half_lo[1][1], g.half_lo[1][2], 0.f), hh1 = make_float4(g.half_hi[1][0], g.half_hi[1][1], g.half_hi[1][2], 0.f);
+                    const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), stat_acc);
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near));
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need);
 #endif
                     if (lane < nk) {
                         if (phase == PH_ITER) {
