@@ -133,6 +133,37 @@ __device__ __forceinline__ long long fixq(float v, int shift) {
     // float->double exact, power-of-two scale exact, round to nearest even (C4)
     return __double2ll_rn(ldexp((double)v, shift));
 }
+// Adds the wave's per-lane 64-bit sums S[0..nsum) into dst[0..nsum) (LDS): an inclusive scan inside each row of 16 lanes - four
+// steps of a 64-bit add whose first operand comes from the lane 1, 2, 4, 8 to the left through the DPP path
+// (v_add_co_u32_dpp + v_addc_co_u32_dpp: no separate move, no LDS crossbar) - leaves the row totals in lanes 15, 31, 47, 63,
+// which add them to dst with one LDS atomic per sum.  Two sums are interleaved per block so that every DPP read is >= 2 VALU
+// instructions away from the write of its register, and every block starts with two wait states (the compiler schedules
+// around inline asm without knowing that it reads through DPP).
+#define CD_DPP_ADD2(a, b, ctrl)                                                                                   \
+    asm volatile("s_nop 1\n\t"                                                                                    \
+                 "v_add_co_u32_dpp %0, vcc, %0, %0 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"         \
+                 "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"   \
+                 "v_add_co_u32_dpp %2, vcc, %2, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0\n\t"         \
+                 "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0"        \
+                 : "+v"(a##lo), "+v"(a##hi), "+v"(b##lo), "+v"(b##hi)::"vcc")
+__device__ __forceinline__ void wave_fold_to_lds(const unsigned long long (&S)[16], int nsum, unsigned long long* dst) {
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        if (k < nsum) {
+            unsigned xlo = (unsigned)S[k], xhi = (unsigned)(S[k] >> 32), ylo = (unsigned)S[k + 1], yhi = (unsigned)(S[k + 1] >> 32);
+            CD_DPP_ADD2(x, y, "row_shr:1");
+            CD_DPP_ADD2(x, y, "row_shr:2");
+            CD_DPP_ADD2(x, y, "row_shr:4");
+            CD_DPP_ADD2(x, y, "row_shr:8");
+            if ((lane & 15) == 15) {
+                atomicAdd(&dst[k], ((unsigned long long)xhi << 32) | xlo);
+                if (k + 1 < nsum) atomicAdd(&dst[k + 1], ((unsigned long long)yhi << 32) | ylo);
+            }
+        }
+    }
+}
+
 __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -492,7 +492,7 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
 // paid: the lexicographic update as ONE 64-bit unsigned compare (the compiler turned "d < best || (d == best && oi < boi)"
 // into two nested exec-mask regions with branches per patch), 6.4 -> 6.0 ms.  What did not: two queries interleaved per trip
 // (same time: the SGPR pressure of two mask/coordinate sets spills to VGPR lanes).
-struct FarQ { float x, y, z, best; unsigned long long m0, m1; unsigned long long lkey; int lbi; };   // lkey = (d2 bits : original index)
+struct FarQ { float x, y, z, best; unsigned long long m0, m1; unsigned long long lkey; };   // lkey = d2 bits : (original index << 13 | stored position)
 
 __device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const QueryRegs& q, int need, int k) {
     f.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
@@ -504,7 +504,7 @@ __device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const Que
     if (nd & 1) f.m0 = __ballot(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
     if (nd & 2) f.m1 = __ballot(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
     // lanes start from (bound, no index): a lane can only be selected if it beat the bound, and the seed point itself does
-    f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull; f.lbi = 0;
+    f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
 }
 __device__ __forceinline__ int far_next_patch(FarQ& f, int psplit) {   // wave-uniform; f.m0 | f.m1 != 0
     int r;
@@ -515,42 +515,32 @@ __device__ __forceinline__ int far_next_patch(FarQ& f, int psplit) {   // wave-u
 __device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
     // lexicographic (d2, original index) minimum, rule C5, as ONE unsigned 64-bit compare: squared distances are non-negative
     // floats (or +inf / NaN-free here), which order like their bit patterns; no branch, no tie special case
+    // The low word carries the stored position below the original index (both < 2^13 for an LDS-resident template; the
+    // position is a function of the index, so the order is still (d2, original index)): the key alone is the whole answer.
     const float d = dist2(f.x, f.y, f.z, t.x, t.y, t.z);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
-    const bool up = key < f.lkey;
-    f.lkey = up ? key : f.lkey; f.lbi = up ? pos : f.lbi;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << 13) | (unsigned)pos);
+    f.lkey = key < f.lkey ? key : f.lkey;
 }
-// lexicographic minimum over the wave.  Only lanes that beat the incoming bound can hold it; when exactly one did (the usual
-// case once seeds are tight) it IS the answer and three v_readlane replace the reduction.
-__device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k) {
-    const float lbest = __uint_as_float((unsigned)(f.lkey >> 32));
-    const int loi = (int)(unsigned)(f.lkey & 0xffffffffull);
-    const unsigned long long imp = __ballot(f.lkey < (((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull));
-    if (imp == 0) return;
-    float dmin;
-    int rbi, roi;
-    if (__popcll(imp) == 1) {
-        const int l = __ffsll((long long)imp) - 1;
-        dmin = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(lbest), l));
-        rbi = __builtin_amdgcn_readlane(f.lbi, l);
-        roi = __builtin_amdgcn_readlane(loi, l);
-    } else {
-        dmin = wave_min_f32_nonneg(lbest);
-        unsigned long long eq = __ballot(lbest == dmin);
-        rbi = 0; roi = 0x7fffffff;
-        while (eq) {
-            const int l = __ffsll((long long)eq) - 1;
-            eq &= eq - 1;
-            const int oi_ = __builtin_amdgcn_readlane(loi, l);
-            const int bi_ = __builtin_amdgcn_readlane(f.lbi, l);
-            if (oi_ <= roi) { roi = oi_; rbi = bi_; }
-        }
-    }
-    if ((int)(threadIdx.x & 63) == k) { q.pbest = dmin; q.pbi = rbi; q.poi = roi; }
+// Minimum over the wave WITHOUT a reduction: the query's owner lane puts the bound key into the wave's LDS word, every lane
+// that beat the bound takes an LDS 64-bit atomic min on it (same address: the LDS serialises them, one per clock), and the
+// word is read back - by all lanes, broadcast - and unpacked.  LDS operations of one wave execute in program order, so no
+// fence is needed.  This replaced ballot + popcount + (DPP minimum + tie loop | three v_readlane) + a masked write-back,
+// which cost more than the box tests (probe: the tail run twice = +1.05 ms of 5.9).
+__device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsigned long long* slot) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long bound = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
+    if (lane == k) __hip_atomic_store(slot, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (f.lkey < bound) __hip_atomic_fetch_min(slot, f.lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const unsigned long long res = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    const bool mine = lane == k && res < bound;
+    const unsigned lo = (unsigned)res;
+    q.pbest = mine ? __uint_as_float((unsigned)(res >> 32)) : q.pbest;
+    q.pbi = mine ? (int)(lo & 0x1fffu) : q.pbi;
+    q.poi = mine ? (int)(lo >> 13) : q.poi;
 }
 
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
-                                               unsigned long long todo, int psplit, int need, int* stat_acc = nullptr) {
+                                               unsigned long long todo, int psplit, int need, unsigned long long* slot, int* stat_acc = nullptr) {
     const int lane = threadIdx.x & 63;
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;
@@ -568,7 +558,7 @@ __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsign
             const int pos = s_kd[r * ICP_SUB + lane];
             far_take(A, s_tpl[pos], pos);
         }
-        far_end(A, q, k);
+        far_end(A, q, k, slot);
     }
 }
 
@@ -1064,8 +1054,8 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
+    __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    (void)wave;
     // every cluster of one launch uses the same (LDS-resident, gridded) template - the host guarantees it
     const IcpCluster c0 = cl[order[0]];
     const IcpGrid g = grids[c0.slot];
@@ -1115,9 +1105,6 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
             CD_PHASE(0)
             const int phase = sl->phase;
             if (phase == PH_EXHAUSTED) { if (sidx) live1 = false; else live0 = false; continue; }
-            unsigned long long S[16];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) S[i] = 0ull;
             if (phase == PH_ITER || phase == PH_FIT) {
                 const int it = sl->it, n = sl->n;
                 float4* pts = src + sl->src_off;
@@ -1190,14 +1177,19 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, stat_acc);
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need);
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, &s_far[wave]);
 #endif
+                    // The pass's 16 moment terms go into the slot's accumulators right away: no sum is carried in registers
+                    // across the searches (32 VGPRs that the search loops would otherwise spill around).
+                    unsigned long long S[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) S[i] = 0ull;
                     if (lane < nk) {
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
@@ -1205,29 +1197,19 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                             const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
 #pragma unroll
                             for (int a = 0; a < 3; ++a) {
-                                S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
-                                S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
+                                S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                                S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
 #pragma unroll
-                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
                             }
-                            S[15] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                            S[15] = (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                         } else {
-                            S[0] += (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                            S[0] = (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                         }
                     }
+                    wave_fold_to_lds(S, phase == PH_ITER ? 16 : 1, sl->acc);
                 }
                 CD_PHASE(1)
-                // this wave's sums -> the slot's accumulators (lane k adds sum k)
-                unsigned long long mine = 0ull;
-                const int nsum = phase == PH_ITER ? 16 : 1;
-#pragma unroll
-                for (int k = 0; k < 16; ++k) {
-                    if (k < nsum) {
-                        const unsigned long long t = wave_sum_u64(S[k]);
-                        if (lane == k) mine = t;
-                    }
-                }
-                if (lane < nsum) atomicAdd(&sl->acc[lane], mine);
                 CD_PHASE(2)
             }
             __threadfence_block();
