@@ -48,6 +48,7 @@ struct FrameState {
     int32_t koff[KICP];    // their offsets in the per-frame ICP source segment
     float origin[3];       // decoded min of the cropped cloud
     int32_t n_cropped;     // N_c as reported (n_c is zeroed when the frame errors out)
+    int32_t cl_done;       // S5: the frame was clustered by k_cluster_lds (0: left to the global-memory kernels)
 };
 
 struct CropLimits {        // double limits folded to equivalent float compares (exact)

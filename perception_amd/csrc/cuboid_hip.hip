@@ -316,18 +316,20 @@ int stage_extract(cd_context* c, int F, const cd_params* p, int gate_mode = -1) 
 }
 
 // S5.  in: d_obj + fs.n_o (device).  out: d_label, d_sizes, fs.n_k/ksize/koff, d_src0/d_src
-int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint) {
+int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint, bool force_global = false) {
     const int T = c->T;
     const int To = std::max(1, (max_no_hint + TILE - 1) / TILE);
     const float cell = (float)(p->cluster_tolerance * (1.0 + 1.0 / 1024.0));
     const float inv_cell = 1.0f / cell;
     const float r2 = (float)(p->cluster_tolerance * p->cluster_tolerance);
     if (p->cluster_enable) {
-        // frames with <= 8192 object points (the usual case) are clustered by one workgroup in LDS ...
-        LAUNCH(c, launch_cluster_lds(c->stream, c->d_obj, c->N, F, c->d_fs, inv_cell, r2, c->d_parent, c->d_csize, c->d_rank));
+        // frames with <= 8192 object points (the usual case) are clustered by one workgroup in LDS, over cells small
+        // enough (edge just under tol / sqrt(3)) that the points of one cell are connected by construction ...
+        const float small_cell = (float)(p->cluster_tolerance / std::sqrt(3.0) * (1.0 - 1.0 / 1024.0));
+        LAUNCH(c, launch_cluster_lds(c->stream, c->d_obj, c->N, F, c->d_fs, 1.0f / small_cell, r2, c->d_parent, c->d_csize, c->d_rank));
     }
-    if (p->cluster_enable && max_no_hint > 8192) {
-        // ... larger ones by the global-memory path (its kernels skip the small frames)
+    if (p->cluster_enable && (max_no_hint > 8192 || force_global)) {
+        // ... larger ones (and the rare frame the LDS kernel gave up on, fs.cl_done == 0) by the global-memory path
         HIPCHK(c, hipMemsetAsync(c->d_head, 0xff, sizeof(int) * (size_t)F * CELL_BUCKETS, c->stream));
         LAUNCH(c, launch_cluster_build(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, c->d_head, c->d_next, c->d_parent, c->d_csize, c->d_rank));
         LAUNCH(c, launch_cluster_hook(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, r2, c->d_head, c->d_next, c->d_parent));
@@ -339,6 +341,21 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint) {
     LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileK, F * KICP, T, nullptr, 0));
     LAUNCH(c, launch_label_scatter(c->stream, c->d_obj, c->N, F, T, To, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src, 0, nullptr));
     return CD_OK;
+}
+
+// stage_cluster + sync; when the LDS kernel gave a frame up (too many cells / too wide a cloud for its table) and the
+// global-memory kernels were not part of the launch, the stage is run again with them.
+int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
+    int st = stage_cluster(c, F, p, max_no);
+    if (st) return st;
+    st = sync_fs(c, F);
+    if (st || !p->cluster_enable || max_no > 8192) return st;
+    bool left = false;
+    for (int f = 0; f < F; ++f) left = left || (c->h_fs[f].n_o > 0 && !c->h_fs[f].cl_done);
+    if (!left) return CD_OK;
+    st = stage_cluster(c, F, p, max_no, true);
+    if (st) return st;
+    return sync_fs(c, F);
 }
 
 // S6.  clusters described by h_cl[0..ncl) (src_off relative to d_src/d_src0).  Fills h_st / h_accf.
@@ -539,9 +556,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     if (st) return st;
     int max_no = 0;
     for (int f = 0; f < F; ++f) max_no = std::max(max_no, c->h_fs[f].n_o);
-    st = stage_cluster(c, F, p, max_no);
-    if (st) return st;
-    st = sync_fs(c, F);   // sync #4: n_plane, n_o, n_k, ksize, koff
+    st = stage_cluster_sync(c, F, p, max_no);   // sync #4: n_plane, n_o, n_k, ksize, koff
     if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
     // Every cluster of every frame gets its ICP (opd.cpp:376-413).  The device extracts the ICP sources KICP clusters per
@@ -1326,9 +1341,7 @@ int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_pa
     if (n == 0) return CD_OK;
     st = load_as(c, xyz, stride, n, c->d_obj, &FrameState::n_o);
     if (st) return st;
-    st = stage_cluster(c, 1, p, n);
-    if (st) return st;
-    st = sync_fs(c, 1);
+    st = stage_cluster_sync(c, 1, p, n);
     if (st) return st;
     HIPCHK(c, copy_sync(c, labels, c->d_label, sizeof(int) * n, hipMemcpyDeviceToHost));
     const int K = c->h_fs[0].n_k;

@@ -15,7 +15,6 @@
 
 namespace cd {
 
-constexpr int CL_LDS_CAP_GLOBAL_SKIP = 8192;   // == CL_LDS_CAP: frames this small are clustered in LDS
 
 __device__ __forceinline__ int ld_agent(const int* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -39,7 +38,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_build(const float4* __restric
                                                          int* __restrict__ rank_of_root) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
-    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
+    if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
     const size_t fbase = (size_t)f * N;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         int cx, cy, cz;
@@ -93,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
                                                         int* parent) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
-    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
+    if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
     const size_t fbase = (size_t)f * N;
     const float4* P = obj + fbase;
     const int* nx = next + fbase;
@@ -134,7 +133,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameSta
                                                            int* __restrict__ parent, int* __restrict__ csize) {
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
-    if (n <= CL_LDS_CAP_GLOBAL_SKIP) return;   // handled by k_cluster_lds
+    if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
     int* par = parent + (size_t)f * N;
     for (int i = blockIdx.x * BLOCK + threadIdx.x; i < n; i += gridDim.x * BLOCK) {
         int r = i;
@@ -149,16 +148,62 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameSta
 }
 
 // ---- LDS variant: one 1024-thread workgroup per frame, for frames with n_o <= CL_LDS_CAP ----------
-// Points, the cell hash (heads + next links) and the union-find parents all live in LDS, so the
-// hooking phase runs at LDS latency and is coherent by construction (one CU).  Produces exactly what
-// build + hook + flatten produce (parent = root = smallest member index, component sizes).
+// Clusters CELLS instead of points.  The cell edge is e = tol/sqrt(3) * (1 - 2^-10), so any two points of one cell are
+// closer than tol (their squared distance is below 3 e^2 = tol^2 (1 - 2^-10)^2; the float roundings of the cell
+// assignment and of dist2 are below 2^-12 relative while cell coordinates stay under 1024, which the kernel checks):
+// a cell is connected by construction and needs no test at all.  Two cells are joined when ONE pair of their points
+// passes the reference's predicate d2 < (float)(tol*tol) (strict, rule C3); points more than two cells apart on any axis
+// cannot pass it ((3-1) e > tol), so a cell looks at the 62 "forward" cells of its 5x5x5 neighbourhood.  The components of
+// the cell graph are exactly those of PCL's point graph; what is saved is the all-pairs work inside and between cells
+// that are already connected (the point-pair version of this kernel spent 0.25 ms per batch on LDS reads).
+//   1. every point inserts its packed cell key in an open-addressing table (LDS CAS), takes a ticket in its cell
+//   2. exclusive scan of the cell counts, points scattered into LDS in cell order
+//   3. hook, four lanes per occupied cell: first the 13 adjacent forward cells, then (after a barrier, when most
+//      cells already share a root and are skipped on a root compare) the 49 cells two steps away
+//   4. per component: smallest original index and size -> parent / csize as build + hook + flatten produce them
+// A frame the table cannot hold (too many cells, or a cloud wider than 1019 cells) is left to the global-memory path:
+// fs.cl_done says which frames are finished.
+#ifdef CD_CLDBG
+// per phase: sum over the workgroups and max over the workgroups of the time thread 0 spent (100 MHz ticks)
+__device__ unsigned long long g_cl_dbg[8][2];
+extern "C" int cd_debug_cluster(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_cl_dbg), sizeof(g_cl_dbg)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[8][2]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_cl_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define CL_PHASE(k) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_cl_dbg[k][0], t_ - t0_); atomicMax(&g_cl_dbg[k][1], t_ - t0_); t0_ = t_; } }
+#else
+#define CL_PHASE(k)
+#endif
 constexpr int CL_LDS_CAP = 8192;
-constexpr int CL_LDS_BUCKETS = 8192;
+constexpr int CL_SLOTS = 4096;          // cell table (power of two)
+constexpr int CL_MAX_CELLS = 3072;      // load factor <= 3/4
+constexpr int CL_COORD_MAX = 1019;      // 10-bit fields hold coordinate + 2, neighbours reach +-2
 constexpr int CL_THREADS = 1024;
 constexpr int CL_PER_THREAD = CL_LDS_CAP / CL_THREADS;
+constexpr int CL_WAVES = CL_THREADS / WAVE;
+constexpr int CL_LANES_PER_CELL = 4;
 
-__device__ __forceinline__ uint32_t cell_hash_lds(int cx, int cy, int cz) {
-    return ((uint32_t)cx * 73856093u ^ (uint32_t)cy * 19349663u ^ (uint32_t)cz * 83492791u) & (CL_LDS_BUCKETS - 1);
+// packed key offsets of the 62 forward cells (code (dx+2) + 5 (dy+2) + 25 (dz+2) in 63..124): the 13 adjacent ones
+// (every |d| <= 1) first, then the 49 that are two cells away on some axis
+constexpr int CL_RING1 = 13, CL_FORWARD = 62;
+struct ClOffsets {
+    int d[CL_FORWARD];
+    constexpr ClOffsets() : d{} {
+        int m = 0;
+        for (int ring = 0; ring < 2; ++ring)
+            for (int code = 63; code < 125; ++code) {
+                const int dx = code % 5 - 2, dy = (code / 5) % 5 - 2, dz = code / 25 - 2;
+                const bool adjacent = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz <= 1;
+                if (adjacent == (ring == 0)) d[m++] = dx + dy * 1024 + dz * 1048576;
+            }
+    }
+};
+__constant__ ClOffsets cl_offsets = ClOffsets();
+
+__device__ __forceinline__ uint32_t cl_slot_hash(int key) {
+    uint32_t h = (uint32_t)key * 2654435761u;
+    return (h >> 17) & (CL_SLOTS - 1);
 }
 // find with path halving; parents live in LDS (coherent within the workgroup).  A halving store
 // only ever re-points a NON-root at one of its ancestors, so it cannot disturb the root CAS.
@@ -172,93 +217,185 @@ __device__ __forceinline__ int lds_find(int* par, int x) {
     }
     return x;
 }
-
-__global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __restrict__ obj, int N,
-                                                            const FrameState* __restrict__ fs, float inv_cell, float r2,
-                                                            int* __restrict__ parent, int* __restrict__ csize,
-                                                            int* __restrict__ rank_of_root) {
-    __shared__ int s_par[CL_LDS_CAP];         // 32 KiB
-    __shared__ int s_next[CL_LDS_CAP];        // 32 KiB (reused as the size counters at the end)
-    __shared__ int s_head[CL_LDS_BUCKETS];    // 32 KiB
-    const int f = blockIdx.x;
-    const int n = fs[f].n_o;
-    if (n <= 0 || n > CL_LDS_CAP) return;     // larger frames take the global-memory path
-    const size_t fbase = (size_t)f * N;
-    const float4* __restrict__ P = obj + fbase;   // read-only in this kernel: plain cached loads
-    const float org[3] = {fs[f].origin[0], fs[f].origin[1], fs[f].origin[2]};
-    for (int i = threadIdx.x; i < CL_LDS_BUCKETS; i += CL_THREADS) s_head[i] = -1;
-    for (int i = threadIdx.x; i < n; i += CL_THREADS) s_par[i] = i;
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += CL_THREADS) {
-        int cx, cy, cz;
-        cell_of(P[i], org, inv_cell, cx, cy, cz);
-        s_next[i] = atomicExch(&s_head[cell_hash_lds(cx, cy, cz)], i);
+// slot of a cell key, or -1 (the table always keeps empty slots: CL_MAX_CELLS < CL_SLOTS)
+__device__ __forceinline__ int cl_lookup(const int* s_key, int key) {
+    int h = (int)cl_slot_hash(key);
+    for (;;) {
+        const int k = s_key[h];
+        if (k == key) return h;
+        if (k == -1) return -1;
+        h = (h + 1) & (CL_SLOTS - 1);
     }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += CL_THREADS) {
-        const float4 p = P[i];
-        int cx, cy, cz;
-        cell_of(p, org, inv_cell, cx, cy, cz);
-        int ri = lds_find(s_par, i);
-        // Each unordered pair of neighbouring cells is examined once: the own cell (pairs j < i) and the
-        // 13 "forward" cells (dz > 0, or dz == 0 && dy > 0, or dz == dy == 0 && dx > 0), all their points.
-        // (Two different cells may share a hash bucket; a pair met twice is just a redundant union.)
-        for (int nb = 0; nb < 14; ++nb) {
-            const int code = nb == 0 ? 13 : 13 + nb;               // 13 = (0,0,0); 14..26 = forward half
-            const int a = code % 3 - 1, b = (code / 3) % 3 - 1, c = code / 9 - 1;
-            int j = s_head[cell_hash_lds(cx + a, cy + b, cz + c)];
-            while (j >= 0) {
-                int jx, jy, jz;
-                const float4 q = P[j];
-                bool take;
-                if (nb == 0) {
-                    take = j < i;
-                } else {   // the bucket may also hold points of other cells (hash collisions): keep exact cell matches only
-                    cell_of(q, org, inv_cell, jx, jy, jz);
-                    take = jx == cx + a && jy == cy + b && jz == cz + c;
-                }
-                // a neighbour that already hangs directly under i's root needs no find and no union (most pairs of a big
-                // cluster once the first unions and path halvings have happened): one LDS read instead of a chain walk
-                if (take && dist2(p.x, p.y, p.z, q.x, q.y, q.z) < r2 && s_par[j] != ri) {
-                    int rj = lds_find(s_par, j);
-                    while (ri != rj) {
-                        const int hi = ri > rj ? ri : rj, lo = ri > rj ? rj : ri;
-                        const int old = atomicCAS(&s_par[hi], hi, lo);   // link the larger root under the smaller
-                        if (old == hi) { ri = lo; rj = lo; break; }
-                        ri = lds_find(s_par, ri);                        // hi had been linked meanwhile: climb and retry
-                        rj = lds_find(s_par, rj);
-                    }
-                    ri = ri < rj ? ri : rj;
-                }
-                j = s_next[j];
-            }
+}
+// cell `ha` against the cell at packed offset `delta`: union the two when one pair of points is closer than tol
+__device__ __forceinline__ void cl_join(const int* s_key, const int* s_val, int* s_par, const float* s_x, const float* s_y,
+                                        const float* s_z, int ha, int key, int delta, float r2, int& ra) {
+    const int hb = cl_lookup(s_key, key + delta);
+    if (hb < 0) return;
+    int rb = lds_find(s_par, hb);
+    if (rb == ra) return;
+    const int a0 = s_val[ha], a1 = s_val[ha + 1], b0 = s_val[hb], b1 = s_val[hb + 1];
+    bool hit = false;
+    for (int a = a0; a < a1 && !hit; ++a) {
+        const float px = s_x[a], py = s_y[a], pz = s_z[a];
+        for (int b = b0; b < b1; b += 2) {   // two candidates per trip (the last one repeats at an odd end)
+            const int bb = b + 1 < b1 ? b + 1 : b;
+            const float d0 = dist2(px, py, pz, s_x[b], s_y[b], s_z[b]);
+            const float d1 = dist2(px, py, pz, s_x[bb], s_y[bb], s_z[bb]);
+            if (d0 < r2 || d1 < r2) { hit = true; break; }
         }
     }
+    if (!hit) return;
+    ra = lds_find(s_par, ra);
+    rb = lds_find(s_par, rb);
+    while (ra != rb) {
+        const int big = ra > rb ? ra : rb, sml = ra > rb ? rb : ra;
+        const int old = atomicCAS(&s_par[big], big, sml);   // link the larger root under the smaller
+        if (old == big) { ra = sml; break; }
+        ra = lds_find(s_par, ra);                          // big had been linked meanwhile: climb, retry
+        rb = lds_find(s_par, rb);
+    }
+}
+
+__global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __restrict__ obj, int N, FrameState* __restrict__ fs,
+                                                            float inv_cell, float r2, int* __restrict__ parent,
+                                                            int* __restrict__ csize, int* __restrict__ rank_of_root) {
+    __shared__ float s_x[CL_LDS_CAP], s_y[CL_LDS_CAP], s_z[CL_LDS_CAP];   // 96 KiB, cell order (s_x / s_y: per-component min / size at the end)
+    __shared__ int s_key[CL_SLOTS];                                       // packed cell of the slot, -1 = empty
+    __shared__ int s_val[CL_SLOTS + 1];                                   // points in the slot's cell, then their start
+    __shared__ int s_par[CL_SLOTS];                                       // union-find over slots
+    __shared__ unsigned short s_cells[CL_MAX_CELLS];                      // occupied slots, dense
+    __shared__ int s_w[CL_WAVES];
+    __shared__ int s_ncell, s_bail;
+    const int f = blockIdx.x;
+    const int n = fs[f].n_o;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (n <= 0 || n > CL_LDS_CAP) {           // larger frames take the global-memory path
+        if (tid == 0) fs[f].cl_done = n <= 0 ? 1 : 0;
+        return;
+    }
+    const size_t fbase = (size_t)f * N;
+    const float4* __restrict__ P = obj + fbase;
+    const float org[3] = {fs[f].origin[0], fs[f].origin[1], fs[f].origin[2]};
+#ifdef CD_CLDBG
+    unsigned long long t0_ = wall_clock64();
+#endif
+    for (int i = tid; i < CL_SLOTS; i += CL_THREADS) { s_key[i] = -1; s_val[i] = 0; s_par[i] = i; }
+    if (tid == 0) { s_ncell = 0; s_bail = 0; }
+    __syncthreads();
+    float4 pt[CL_PER_THREAD];
+    int sl[CL_PER_THREAD], tk[CL_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = tid + k * CL_THREADS;
+        sl[k] = 0; tk[k] = 0;
+        if (i < n) {
+            pt[k] = P[i];
+            int cx, cy, cz;
+            cell_of(pt[k], org, inv_cell, cx, cy, cz);
+            bool ok = cx >= 0 && cy >= 0 && cz >= 0 && cx <= CL_COORD_MAX && cy <= CL_COORD_MAX && cz <= CL_COORD_MAX;
+            if (ok) {
+                const int key = (cx + 2) | ((cy + 2) << 10) | ((cz + 2) << 20);
+                int h = (int)cl_slot_hash(key);
+                ok = false;
+                for (int probe = 0; probe < CL_SLOTS; ++probe) {
+                    const int old = atomicCAS(&s_key[h], -1, key);
+                    if (old == -1) {   // this point opened the cell
+                        const int ci = atomicAdd(&s_ncell, 1);
+                        if (ci < CL_MAX_CELLS) s_cells[ci] = (unsigned short)h;
+                        ok = true;
+                        break;
+                    }
+                    if (old == key) { ok = true; break; }
+                    h = (h + 1) & (CL_SLOTS - 1);
+                }
+                sl[k] = h;
+                if (ok) tk[k] = atomicAdd(&s_val[h], 1);
+            }
+            if (!ok) s_bail = 1;
+        }
+    }
+    __syncthreads();
+    const int ncell = s_ncell;
+    if (s_bail || ncell > CL_MAX_CELLS) {     // uniform: leave the frame to the global-memory kernels
+        if (tid == 0) fs[f].cl_done = 0;
+        return;
+    }
+    {   // exclusive scan of the slot counts: four consecutive slots per thread
+        const int q = 4 * tid;
+        const int c0 = s_val[q], c1 = s_val[q + 1], c2 = s_val[q + 2], c3 = s_val[q + 3];
+        const int sum = c0 + c1 + c2 + c3;
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int v = 0; v < w; ++v) base += s_w[v];
+        s_val[q] = base;
+        s_val[q + 1] = base + c0;
+        s_val[q + 2] = base + c0 + c1;
+        s_val[q + 3] = base + c0 + c1 + c2;
+        if (tid == 0) s_val[CL_SLOTS] = n;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = tid + k * CL_THREADS;
+        if (i < n) {
+            const int pos = s_val[sl[k]] + tk[k];
+            s_x[pos] = pt[k].x; s_y[pos] = pt[k].y; s_z[pos] = pt[k].z;
+        }
+    }
+    __syncthreads();
+    CL_PHASE(0)
+    // hook.  item = (cell, lane of the cell); the lanes of a cell share its forward offsets round robin.
+    const int items = ncell * CL_LANES_PER_CELL;
+    for (int ring = 0; ring < 2; ++ring) {
+        const int j0 = ring == 0 ? 0 : CL_RING1, j1 = ring == 0 ? CL_RING1 : CL_FORWARD;
+        for (int it = tid; it < items; it += CL_THREADS) {
+            const int ha = (int)s_cells[it / CL_LANES_PER_CELL], g = it % CL_LANES_PER_CELL;
+            const int key = s_key[ha];
+            int ra = lds_find(s_par, ha);
+#pragma unroll 1
+            for (int j = j0 + g; j < j1; j += CL_LANES_PER_CELL)
+                cl_join(s_key, s_val, s_par, s_x, s_y, s_z, ha, key, cl_offsets.d[j], r2, ra);
+        }
+        __syncthreads();
+    }
+    CL_PHASE(1)
+    // components -> (smallest original member index, size), kept at the root slot in the dead coordinate arrays
+    int* s_min = reinterpret_cast<int*>(s_x);
+    int* s_cnt = reinterpret_cast<int*>(s_y);
+    for (int q = tid; q < CL_SLOTS; q += CL_THREADS) { s_min[q] = 0x7fffffff; s_cnt[q] = 0; }
     __syncthreads();
     int root[CL_PER_THREAD];
 #pragma unroll
     for (int k = 0; k < CL_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CL_THREADS;
-        root[k] = i < n ? lds_find(s_par, i) : 0;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < n; i += CL_THREADS) s_next[i] = 0;   // links are dead: reuse as size counters
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CL_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CL_THREADS;
-        if (i < n) atomicAdd(&s_next[root[k]], 1);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < CL_PER_THREAD; ++k) {
-        const int i = threadIdx.x + k * CL_THREADS;
+        const int i = tid + k * CL_THREADS;
+        root[k] = 0;
         if (i < n) {
-            parent[fbase + i] = root[k];
-            csize[fbase + i] = s_next[i];
+            root[k] = lds_find(s_par, sl[k]);
+            atomicMin(&s_min[root[k]], i);
+            atomicAdd(&s_cnt[root[k]], 1);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) {
+        const int i = tid + k * CL_THREADS;
+        if (i < n) {
+            const int r = s_min[root[k]];
+            parent[fbase + i] = r;
+            csize[fbase + i] = r == i ? s_cnt[root[k]] : 0;
             rank_of_root[fbase + i] = -1;
         }
     }
+    if (tid == 0) fs[f].cl_done = 1;
+    CL_PHASE(2)
 }
 
 // one block per frame
@@ -416,9 +553,8 @@ static inline int grid_for(int n_max) {
     return g < 1 ? 1 : (g > 1024 ? 1024 : g);
 }
 
-void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, const FrameState* fs, float inv_cell, float r2,
+void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
                         int* parent, int* csize, int* rank_of_root) {
-    static_assert(CL_LDS_CAP == CL_LDS_CAP_GLOBAL_SKIP, "LDS / global split must agree");
     hipLaunchKernelGGL(k_cluster_lds, dim3(F), dim3(CL_THREADS), 0, s, obj, N, fs, inv_cell, r2, parent, csize, rank_of_root);
 }
 void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,

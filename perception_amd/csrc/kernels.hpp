@@ -35,7 +35,7 @@ void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int 
                             float z2hi, const BBoxGate& gate, const int* off_plane, const int* off_obj, int* plane_idx, float4* obj);
 
 // k_cluster.hip
-void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, const FrameState* fs, float inv_cell, float r2,
+void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
                         int* parent, int* csize, int* rank_of_root);
 void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
                           int* head, int* next, int* parent, int* csize, int* rank_of_root);

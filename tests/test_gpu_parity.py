@@ -156,6 +156,37 @@ def test_cluster_labels_bit_exact(ctx, O, frames4, template):
     assert k == 1 and sizes[0] == 25120 and (lab == 0).all()
 
 
+@pytest.mark.gpu
+def test_cluster_cell_kernel_edges(ctx, O):
+    """S5 in LDS clusters cells of edge tol/sqrt(3) (k_cluster.hip): exact-tie distances on a quantised lattice, dense
+    slabs with many pairs near the radius, a cloud wider than its 10-bit cell coordinates and one with more cells than
+    its table (both handed to the global-memory kernels) - labels and sizes identical to the oracle every time."""
+    prm = capi.default_params()
+    prm.cluster_min_size, prm.cluster_max_size = 1, 25000
+    rng = np.random.RandomState(11)
+    cases = {}
+    # multiples of 2.5 mm: many pairs at exactly 0.02 (not connected, strict <) and at 0.0175 / 0.01903 (connected)
+    q = rng.randint(0, 60, (5000, 3)).astype(np.float32) * np.float32(0.0025)
+    cases["lattice"] = np.unique(q, axis=0)[:7000]
+    slab = rng.uniform(0, 1, (6000, 3)).astype(np.float32) * np.float32([0.6, 0.6, 0.03])
+    cases["slab"] = slab
+    cases["sparse_slab"] = (rng.uniform(0, 1, (2500, 3)) * [1.2, 1.2, 0.02]).astype(np.float32)
+    wide = np.concatenate([_blob([0, 0, .5], 400, .01, rng), _blob([13.0, 0, .5], 300, .01, rng),
+                           _blob([0, -12.5, .5], 300, .01, rng)])
+    cases["wide"] = wide[rng.permutation(len(wide))]
+    cases["many_cells"] = np.concatenate([_blob([0, 0, .5], 500, .01, rng),
+                                          rng.uniform(-2, 2, (5000, 3)).astype(np.float32)])
+    cases["two_points"] = np.float32([[0, 0, 0], [0.0199, 0, 0]])
+    cases["negative_coords"] = (slab[:3000] - np.float32([5.0, 7.0, 0.5])).astype(np.float32)
+    for name, pts in cases.items():
+        pts = np.ascontiguousarray(pts, np.float32)
+        lab, sizes, k = ctx.cluster(pts, prm, sizes_capacity=8192)
+        l0, s0, k0 = O.cluster(pts, prm, mode=0 if len(pts) <= 7000 else 1, sizes_capacity=8192)
+        assert k == k0, (name, k, k0)
+        assert np.array_equal(lab, l0), name
+        assert np.array_equal(sizes, s0), name
+
+
 def test_icp_bit_exact_and_known_answer(ctx, O, template, frames4):
     prm = capi.default_params()
     r = O.process_frame(frames4[0], prm, template, want_clouds=True)
