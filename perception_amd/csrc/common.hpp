@@ -49,10 +49,20 @@ struct FrameState {
     float origin[3];       // decoded min of the cropped cloud
     int32_t n_cropped;     // N_c as reported (n_c is zeroed when the frame errors out)
     int32_t cl_done;       // S5: the frame was clustered by k_cluster_lds (0: left to the global-memory kernels)
+    int32_t crop_overflow; // single-pass crop: a y cell index did not fit its bit field (the host redoes the batch in two passes)
 };
 
 struct CropLimits {        // double limits folded to equivalent float compares (exact)
     float zlo, zhi, xlo, xhi;
+};
+
+// Single-pass crop (k_crop_fused): the voxel grid origin (min of the cropped cloud) is not known while the points are
+// compacted, so a point's three floor(p / leaf) values are stored as absolute bit fields - x and z relative to the floors of
+// the crop limits, y biased by half its field - and turned into PCL's idx = i + j dx + k dx dy by the first sort pass.
+struct KeyPack {
+    int32_t enabled;
+    int32_t bi, bj;        // field widths of x and y (z takes the rest)
+    int32_t ilo, jlo, klo; // value of field 0 on each axis
 };
 
 struct BBoxGate {          // bbox_filter.cpp within_bbox(), see cd_params.bbox_*

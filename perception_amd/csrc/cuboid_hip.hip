@@ -32,6 +32,7 @@ struct cd_context {
     FrameState* h_fs = nullptr;
     // ordered-compaction tile counters
     int *d_tileA = nullptr, *d_tileB = nullptr, *d_tileK = nullptr;
+    bool crop_two_pass = false;   // CUBOID_CROP_TWO_PASS=1: always the two-pass crop
     // point buffers (float4 = x,y,z,rgb bits)
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_hist = nullptr;
@@ -175,14 +176,52 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
         std::memset(&s, 0, sizeof(s));
         for (int a = 0; a < 3; ++a) { s.mn[a] = 0xffffffffu; s.mx[a] = 0u; }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-    LAUNCH(c, launch_crop_count(c->stream, d_in, stride, N, F, rgb_off, lim, T, c->d_fs, c->d_tileA));
-    LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_c), FS_PITCH));
-    LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
-    LAUNCH(c, launch_crop_compact(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]));
-    int st = sync_fs(c, F);   // sync #1: n_c, key_bits (sort pass count)
-    if (st) return st;
+    // Single pass (one read of the input) when the crop limits bound the x and z cell indices tightly enough to leave the
+    // unbounded y index a wide bit field; a frame whose y does not fit anyway sends the batch through the two-pass path.
+    KeyPack kp;
+    std::memset(&kp, 0, sizeof(kp));
+    {
+        const float inv = 1.0f / p->leaf_size;
+        const float fl[4] = {std::floor(lim.xlo * inv), std::floor(lim.xhi * inv), std::floor(lim.zlo * inv), std::floor(lim.zhi * inv)};
+        bool ok = !c->crop_two_pass;
+        for (float v : fl) ok = ok && std::fabs(v) < 1.0e9f;
+        if (ok && fl[1] >= fl[0] && fl[3] >= fl[2]) {
+            const long long ri = (long long)fl[1] - (long long)fl[0] + 1, rk = (long long)fl[3] - (long long)fl[2] + 1;
+            int bi = 1, bk = 1;
+            while ((1ll << bi) < ri) ++bi;
+            while ((1ll << bk) < rk) ++bk;
+            if (bi + bk <= 20) {
+                kp.enabled = 1;
+                kp.bi = bi; kp.bj = 32 - bi - bk;
+                kp.ilo = (int)fl[0]; kp.klo = (int)fl[2]; kp.jlo = -(1 << (kp.bj - 1));
+            }
+        }
+    }
+    int st = CD_OK;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+        if (kp.enabled) {
+            LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
+        } else {
+            LAUNCH(c, launch_crop_count(c->stream, d_in, stride, N, F, rgb_off, lim, T, c->d_fs, c->d_tileA));
+            LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_c), FS_PITCH));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
+            LAUNCH(c, launch_crop_compact(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]));
+        }
+        st = sync_fs(c, F);   // sync #1: n_c, key_bits (sort pass count)
+        if (st) return st;
+        bool over = false;
+        for (int f = 0; f < F; ++f) over = over || c->h_fs[f].crop_overflow != 0;
+        if (!over) break;
+        kp.enabled = 0;       // rare: redo the crop in two passes (the FrameState init in h_fs was overwritten by the sync)
+        for (int f = 0; f < F; ++f) {
+            FrameState& s = c->h_fs[f];
+            std::memset(&s, 0, sizeof(s));
+            for (int a = 0; a < 3; ++a) { s.mn[a] = 0xffffffffu; s.mx[a] = 0u; }
+        }
+    }
     int max_nc = 0, max_bits = 0;
     for (int f = 0; f < F; ++f) { max_nc = std::max(max_nc, c->h_fs[f].n_c); max_bits = std::max(max_bits, c->h_fs[f].key_bits); }
     const int Tc = std::max(1, (max_nc + TILE - 1) / TILE);
@@ -190,7 +229,8 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     int cur = 0;
     const uint32_t* vin = nullptr;
     for (int shift = 0; shift < max_bits; shift += RADIX_BITS) {
-        LAUNCH(c, launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, Ts, Tsc, shift, c->d_fs, c->d_hist));
+        LAUNCH(c, launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, Ts, Tsc, shift, c->d_fs, c->d_hist, kp));
+        kp.enabled = 0;       // later passes read voxel indices
         cur ^= 1;
         vin = c->d_val[cur];
     }
@@ -886,6 +926,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;

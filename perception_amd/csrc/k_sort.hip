@@ -18,8 +18,29 @@ namespace cd {
 
 constexpr int SORT_WAVES = SORT_BLOCK / WAVE;
 
+// The first pass after a single-pass crop reads absolute coordinate fields (KeyPack) and turns them into PCL's voxel index,
+// with the arithmetic of VoxelGrid::applyFilter: ijk = (int)(floor(p * inv_leaf) - min_b) in float, idx = i + j dx + k dx dy.
+struct KeyGrid {
+    float mb0, mb1, mb2;
+    int d0, d01;
+};
+__device__ __forceinline__ KeyGrid key_grid(const FrameState& s) {
+    KeyGrid g;
+    g.mb0 = (float)s.min_b[0]; g.mb1 = (float)s.min_b[1]; g.mb2 = (float)s.min_b[2];
+    g.d0 = s.div_b[0]; g.d01 = s.div_b[0] * s.div_b[1];
+    return g;
+}
+__device__ __forceinline__ uint32_t voxel_key(uint32_t a, const KeyPack& kp, const KeyGrid& g) {
+    const int fx = (int)(a & ((1u << kp.bi) - 1u)) + kp.ilo;
+    const int fy = (int)((a >> kp.bi) & ((1u << kp.bj) - 1u)) + kp.jlo;
+    const int fz = (int)(a >> (kp.bi + kp.bj)) + kp.klo;
+    const int i0 = (int)__fsub_rn((float)fx, g.mb0), i1 = (int)__fsub_rn((float)fy, g.mb1), i2 = (int)__fsub_rn((float)fz, g.mb2);
+    return (uint32_t)(i0 + i1 * g.d0 + i2 * g.d01);
+}
+
 __global__ void __launch_bounds__(SORT_BLOCK) k_radix_hist(const uint32_t* __restrict__ kin, int N, int T, int shift,
-                                                           const FrameState* __restrict__ fs, uint32_t* __restrict__ hist) {
+                                                           const FrameState* __restrict__ fs, uint32_t* __restrict__ hist,
+                                                           KeyPack kp) {
     __shared__ uint32_t s_h[RADIX];
     const int f = blockIdx.y, tile = blockIdx.x;
     const int n = fs[f].n_c;
@@ -28,10 +49,14 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_hist(const uint32_t* __res
     __syncthreads();
     const uint32_t* k = kin + (size_t)f * N;
     const int base = tile * SORT_TILE + (threadIdx.x >> 6) * WAVE_SPAN + (threadIdx.x & 63);
+    const KeyGrid g = key_grid(fs[f]);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
-        if (e < n) atomicAdd(&s_h[(k[e] >> shift) & (RADIX - 1)], 1u);
+        if (e < n) {
+            const uint32_t key = kp.enabled ? voxel_key(k[e], kp, g) : k[e];
+            atomicAdd(&s_h[(key >> shift) & (RADIX - 1)], 1u);
+        }
     }
     __syncthreads();
     if (threadIdx.x < RADIX) hist[((size_t)f * T + tile) * RADIX + threadIdx.x] = s_h[threadIdx.x];
@@ -67,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_radix_scan(int T, const FrameState* _
 __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
                                                          int T, int shift, const FrameState* __restrict__ fs,
-                                                         const uint32_t* __restrict__ hist) {
+                                                         const uint32_t* __restrict__ hist, KeyPack kp) {
     __shared__ uint32_t s_wh[SORT_WAVES][RADIX];
     __shared__ uint32_t s_goff[RADIX];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -79,12 +104,14 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     __syncthreads();
     const int base = tile * SORT_TILE + w * WAVE_SPAN + lane;
     const uint64_t lt = lanemask_lt();
+    const KeyGrid g = key_grid(fs[f]);
     uint32_t key[ITEMS], rank[ITEMS];
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         const bool valid = e < n;
         key[j] = valid ? kin[fbase + e] : 0xffffffffu;
+        if (kp.enabled && valid) key[j] = voxel_key(key[j], kp, g);
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
         uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -127,11 +154,12 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
 }
 
 // T = sort tiles per frame the histogram is laid out for, Tact = sort tiles that hold data (max over the frames)
+// kp.enabled: kin holds the absolute coordinate fields of k_crop_fused (first pass only); kout gets voxel indices
 void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
-                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, N, T, shift, fs, hist);
+                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist, KeyPack kp) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, N, T, shift, fs, hist, kp);
     hipLaunchKernelGGL(k_radix_scan, dim3(F), dim3(BLOCK), 0, s, T, fs, hist);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, N, T, shift, fs, hist);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, N, T, shift, fs, hist, kp);
 }
 
 }  // namespace cd

@@ -205,6 +205,124 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
     }
 }
 
+// ---- single pass: crop + ordered compaction + min/max + absolute voxel coordinates -------
+// One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from a chained scan
+// ("decoupled look-back"): a tile publishes its own total (flag 1), walks back over its predecessors adding totals until it
+// meets an inclusive prefix (flag 2), and publishes its own inclusive prefix.  state words: flag << 30 | value.
+// Workgroup b is tile b / F of frame b % F: the tiles in flight at any time are a few per frame, so a tile's predecessors
+// are usually long done and its look-back ends at the first word.  A workgroup only ever waits for workgroups with a
+// smaller id, and the hardware starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup
+// with the smallest id is always running: the waits are finite.  (An atomic ticket would make that independent of the
+// dispatch order, at the price of a dependent memory round trip before the first load; the spin bound below turns a
+// wait that does not end into the two-pass path instead.)
+__global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ in, size_t stride, int N, int pitch,
+                                                      int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
+                                                      FrameState* __restrict__ fs, int* __restrict__ state,
+                                                      float4* __restrict__ cpt,
+                                                      uint32_t* __restrict__ keys) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
+    __shared__ int s_excl;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int F = gridDim.x / Tin;
+    const int f = blockIdx.x % F, tile = blockIdx.x / F;
+    const size_t fbase = (size_t)f * N;        // input records
+    const size_t obase = (size_t)f * pitch;    // internal arrays
+    const int base = tile * TILE + w * WAVE_SPAN;
+    float px[ITEMS], py[ITEMS], pz[ITEMS];
+    uint32_t pc[ITEMS];
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+    float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE + lane;
+        bool keep = false;
+        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0;
+        if (e < N) {
+            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
+            keep = crop_keep(px[j], py[j], pz[j], lim);
+            if (keep) {
+                mn[0] = fminf(mn[0], px[j]); mn[1] = fminf(mn[1], py[j]); mn[2] = fminf(mn[2], pz[j]);
+                mx[0] = fmaxf(mx[0], px[j]); mx[1] = fmaxf(mx[1], py[j]); mx[2] = fmaxf(mx[2], pz[j]);
+            }
+        }
+        bal[j] = __ballot(keep);
+        wtot += __popcll(bal[j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    }
+    if (lane == 0) {
+        s_cnt[w] = wtot;
+        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k];
+        unsigned* st = reinterpret_cast<unsigned*>(state) + (size_t)f * T;
+        const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;
+        int excl = 0;
+        if (tile > 0) {
+            __hip_atomic_store(st + tile, FLAG_TOTAL | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int q = tile - 1; q >= 0; --q) {   // q == 0 always carries FLAG_PREFIX: the bound is a guard only
+                unsigned v;
+                int spins = 0;
+                do {
+                    v = __hip_atomic_load(st + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // the ticket order makes this wait finite; should it ever not be, give the batch to the two-pass path
+                    if (++spins > (1 << 20)) { fs[f].crop_overflow = 1; v = FLAG_PREFIX; }
+                } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0u);
+                excl += (int)(v & VALUE);
+                if (v & FLAG_PREFIX) break;
+            }
+        }
+        __hip_atomic_store(st + tile, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_excl = excl;
+        if (tile == Tin - 1) fs[f].n_c = excl + tot;
+        if (tot > 0) {
+            for (int a = 0; a < 3; ++a) {
+                float lo = s_mn[0][a], hi = s_mx[0][a];
+                for (int k = 1; k < WAVES_PER_BLOCK; ++k) { lo = fminf(lo, s_mn[k][a]); hi = fmaxf(hi, s_mx[k][a]); }
+                atomicMin(&fs[f].mn[a], f2ord(lo));
+                atomicMax(&fs[f].mx[a], f2ord(hi));
+            }
+        }
+    }
+    __syncthreads();
+    int pos = s_excl;
+    for (int k = 0; k < w; ++k) pos += s_cnt[k];
+    const float inv = __fdiv_rn(1.0f, leaf);
+    const float jlo = (float)kp.jlo, jhi = (float)(kp.jlo + ((1 << kp.bj) - 1));
+    const uint64_t lt = lanemask_lt();
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) {
+            const int r = pos + __popcll(bal[j] & lt);
+            const float fy = floorf(__fmul_rn(py[j], inv));
+            const bool fits = fy >= jlo && fy <= jhi;
+            over = over || !fits;
+            const uint32_t ui = (uint32_t)((int)floorf(__fmul_rn(px[j], inv)) - kp.ilo);
+            const uint32_t uj = fits ? (uint32_t)((int)fy - kp.jlo) : 0u;
+            const uint32_t uk = (uint32_t)((int)floorf(__fmul_rn(pz[j], inv)) - kp.klo);
+            if (r < pitch) {
+                cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
+                keys[obase + r] = ui | (uj << kp.bi) | (uk << (kp.bi + kp.bj));
+            }
+        }
+        pos += __popcll(bal[j]);
+    }
+    if (__ballot(over) != 0ull && lane == 0) fs[f].crop_overflow = 1;
+}
+
 // ---- voxel run heads in the sorted key array -------------------------------------------
 __device__ __forceinline__ bool is_head(const uint32_t* __restrict__ k, int e, int n) {
     return e < n && (e == 0 || k[e] != k[e - 1]);
@@ -329,6 +447,12 @@ void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, in
     const int Tin = (N + TILE - 1) / TILE;
     hipLaunchKernelGGL(k_crop_compact, dim3(Tin, F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, leaf,
                        fs, tile_off, cpt, keys);
+}
+void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys) {
+    const int Tin = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL(k_crop_fused, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
+                       leaf, kp, fs, state, cpt, keys);
 }
 void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
                               int* tile_cnt) {

@@ -9,6 +9,8 @@ void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int 
                        FrameState* fs, int* tile_cnt);
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
 void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf);
+void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys);
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
 void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
@@ -18,7 +20,7 @@ void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* 
 
 // k_sort.hip : segmented (per frame) stable LSD radix sort pass on (key, value) pairs
 void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
-                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist);
+                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist, KeyPack kp);
 
 // k_plane.hip
 void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,

@@ -46,6 +46,44 @@ def test_crop_voxel_bit_exact(ctx, O, frames4):
         assert np.array_equal(rgb, ro)
 
 
+def test_crop_single_pass_equals_two_pass_and_y_overflow(ctx, O, template, frames4, monkeypatch):
+    """The crop reads the input once (k_crop_fused: chained scan + absolute coordinate fields, re-keyed by the first sort
+    pass).  Same outputs as the two-pass crop on a batch; a frame whose y cells do not fit the bit field (|y| > 327 m at
+    leaf 0.005) sends the batch back through the two-pass path and still matches the oracle; empty and tiny frames."""
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    batch = np.stack(frames4, 0)
+    res1, pi1, lb1 = ctx.process_batch(batch, prm, want_indices=True)
+    monkeypatch.setenv("CUBOID_CROP_TWO_PASS", "1")
+    c2 = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=4)
+    monkeypatch.delenv("CUBOID_CROP_TWO_PASS")
+    try:
+        c2.set_template(0, template)
+        res2, pi2, lb2 = c2.process_batch(batch, prm, want_indices=True)
+        assert np.array_equal(capi.results_to_array(res1), capi.results_to_array(res2))
+        assert np.array_equal(pi1, pi2) and np.array_equal(lb1, lb2)
+        for leaf in (0.005, 0.001, 0.02):
+            prm.leaf_size = leaf
+            a, b = ctx.crop_voxel(frames4[2], prm, want_rgb=True), c2.crop_voxel(frames4[2], prm, want_rgb=True)
+            assert a[2] == b[2] and np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and np.array_equal(a[1], b[1])
+    finally:
+        c2.close()
+    prm.leaf_size = 0.005
+    far = frames4[0].copy()
+    keep = np.flatnonzero((np.abs(far[:, 0]) < 0.2) & (far[:, 2] > 0) & (far[:, 2] < 0.9))
+    far[keep[::97], 1] = np.float32(400.0)     # 80000 cells away: outside the 17-bit y field
+    far[keep[5::101], 1] = np.float32(-300.0)
+    vox, rgb, nc = ctx.crop_voxel(far, prm, want_rgb=True)
+    st, vo, ro, nco, _ = O.crop_voxel(far, prm, want_rgb=True)
+    assert st == 0 and nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+    # ragged tile ends: sizes around the 2048-point tile
+    for n in (1, 63, 2047, 2048, 2049, 6145):
+        pts = frames4[3][1000:1000 + 40 * n:40][:n].copy()
+        vox, rgb, nc = ctx.crop_voxel(pts, prm, want_rgb=True)
+        st, vo, ro, nco, _ = O.crop_voxel(pts, prm, want_rgb=True)
+        assert st == 0 and nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)), n
+
+
 def test_crop_voxel_edge_cases(ctx, O):
     prm = capi.default_params()
     # all-NaN, single point, limits exactly on float boundaries, stride 12 (no rgb)
