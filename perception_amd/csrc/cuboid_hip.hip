@@ -1008,7 +1008,9 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
         }
         float pitch = 0.002f;
         if (!nn2.empty()) { std::nth_element(nn2.begin(), nn2.begin() + nn2.size() / 2, nn2.end()); pitch = std::sqrt(nn2[nn2.size() / 2]); }
-        float cell = std::fmax(2.0f * pitch, 1.0e-4f);
+        float cell_factor = 2.0f;
+        if (const char* e = std::getenv("CUBOID_ICP_CELL_FACTOR")) cell_factor = (float)std::atof(e);   // tuning only
+        float cell = std::fmax(cell_factor * pitch, 1.0e-4f);
         int nd[3];
         for (;;) {
             long long tot = 1;

@@ -50,13 +50,23 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_hist(const uint32_t* __res
     const uint32_t* k = kin + (size_t)f * N;
     const int base = tile * SORT_TILE + (threadIdx.x >> 6) * WAVE_SPAN + (threadIdx.x & 63);
     const KeyGrid g = key_grid(fs[f]);
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
+        // Neighbouring elements mostly carry the same digit (neighbouring pixels, or an input ordered by the lower digits):
+        // only the first lane of a run of equal digits adds, the run length at once - the LDS serialises lanes that add to
+        // one address, which was the whole cost of this kernel.
+        uint32_t d = 0xffffffffu;   // past the end: a run of its own that adds nothing
         if (e < n) {
             const uint32_t key = kp.enabled ? voxel_key(k[e], kp, g) : k[e];
-            atomicAdd(&s_h[(key >> shift) & (RADIX - 1)], 1u);
+            d = (key >> shift) & (RADIX - 1);
         }
+        const uint32_t prev = (uint32_t)__shfl_up((int)d, 1, 64);
+        const uint64_t heads = __ballot(lane == 0 || d != prev);
+        const uint64_t above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+        const int next = above ? __ffsll((long long)above) - 1 : 64;
+        if (((heads >> lane) & 1ull) && e < n) atomicAdd(&s_h[d], (uint32_t)(next - lane));
     }
     __syncthreads();
     if (threadIdx.x < RADIX) hist[((size_t)f * T + tile) * RADIX + threadIdx.x] = s_h[threadIdx.x];
@@ -93,8 +103,11 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
                                                          int T, int shift, const FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ hist, KeyPack kp) {
-    __shared__ uint32_t s_wh[SORT_WAVES][RADIX];
-    __shared__ uint32_t s_goff[RADIX];
+    __shared__ unsigned short s_wh[SORT_WAVES][RADIX];   // per-wave bin counts, then the wave's offset inside the bin
+    __shared__ uint32_t s_goff[RADIX];                   // where the tile's part of each bin starts in the frame
+    __shared__ uint32_t s_bstart[RADIX];                 // where each bin starts inside the tile
+    __shared__ uint32_t s_k[SORT_TILE], s_v[SORT_TILE];  // the tile, ordered by bin (64 KiB)
+    __shared__ uint32_t s_ws[RADIX / WAVE];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * SORT_TILE >= n) return;
@@ -124,31 +137,60 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
         uint32_t bin_base = 0;
         if (valid && lane == leader) {
             bin_base = s_wh[w][d];
-            s_wh[w][d] = bin_base + (uint32_t)__popcll(peers);
+            s_wh[w][d] = (unsigned short)(bin_base + (uint32_t)__popcll(peers));
         }
         bin_base = __shfl(bin_base, leader, 64);
         rank[j] = bin_base + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
-    if (threadIdx.x < RADIX) {   // per-digit exclusive prefix over the waves
+    if (threadIdx.x < RADIX) {   // per-digit exclusive prefix over the waves, then over the digits
         const int d = threadIdx.x;
         uint32_t run = 0;
 #pragma unroll
         for (int q = 0; q < SORT_WAVES; ++q) {
             const uint32_t c = s_wh[q][d];
-            s_wh[q][d] = run;
+            s_wh[q][d] = (unsigned short)run;
             run += c;
         }
+        uint32_t inc = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_ws[w] = inc;
+        s_bstart[d] = inc - run;   // completed below with the totals of the lower waves
     }
     __syncthreads();
+    if (threadIdx.x < RADIX) {
+        uint32_t add = 0;
+        for (int q = 0; q < w; ++q) add += s_ws[q];
+        s_bstart[threadIdx.x] += add;
+    }
+    __syncthreads();
+    // the tile in bin order, staged in LDS: the global stores below are then contiguous runs (one run per bin) instead of
+    // 64 scattered 4-byte stores per instruction
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         if (e < n) {
             const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-            const uint32_t dst = s_goff[d] + s_wh[w][d] + rank[j];
-            kout[fbase + dst] = key[j];
-            vout[fbase + dst] = vin ? vin[fbase + e] : (uint32_t)e;
+            const uint32_t lp = s_bstart[d] + s_wh[w][d] + rank[j];
+            s_k[lp] = key[j];
+            s_v[lp] = vin ? vin[fbase + e] : (uint32_t)e;
+        }
+    }
+    __syncthreads();
+    const int cnt = min(SORT_TILE, n - tile * SORT_TILE);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int lp = threadIdx.x + j * SORT_BLOCK;
+        if (lp < cnt) {
+            const uint32_t k = s_k[lp];
+            const uint32_t d = (k >> shift) & (RADIX - 1);
+            const uint32_t dst = s_goff[d] + ((uint32_t)lp - s_bstart[d]);
+            kout[fbase + dst] = k;
+            vout[fbase + dst] = s_v[lp];
         }
     }
 }
