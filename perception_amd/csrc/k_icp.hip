@@ -529,16 +529,28 @@ __device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
 __device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsigned long long* slot) {
     const int lane = threadIdx.x & 63;
     const unsigned long long bound = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
-    if (lane == k) __hip_atomic_store(slot, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    if (f.lkey < bound) __hip_atomic_fetch_min(slot, f.lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    const unsigned long long res = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    const bool mine = lane == k && res < bound;
+    // lanes whose key beats the bound.  None: the query keeps its seed.  Exactly one (the usual case once the seeds are
+    // tight: the seed point itself, in the one patch that holds it): that key IS the minimum, fetched with two readlanes.
+    // Several: LDS 64-bit min over them.
+    const unsigned long long imp = __ballot(f.lkey < bound);
+    if (imp == 0ull) return;
+    unsigned long long res;
+    if ((imp & (imp - 1ull)) == 0ull) {
+        const int src = __ffsll((long long)imp) - 1;
+        const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(f.lkey >> 32), src);
+        const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)f.lkey, src);
+        res = ((unsigned long long)hi << 32) | lo;
+    } else {
+        if (lane == k) __hip_atomic_store(slot, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        if (f.lkey < bound) __hip_atomic_fetch_min(slot, f.lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        res = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    }
+    const bool mine = lane == k;
     const unsigned lo = (unsigned)res;
     q.pbest = mine ? __uint_as_float((unsigned)(res >> 32)) : q.pbest;
     q.pbi = mine ? (int)(lo & 0x1fffu) : q.pbi;
     q.poi = mine ? (int)(lo >> 13) : q.poi;
 }
-
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
                                                unsigned long long todo, int psplit, int need, unsigned long long* slot, int* stat_acc = nullptr) {
     const int lane = threadIdx.x & 63;
