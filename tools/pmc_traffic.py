@@ -27,7 +27,7 @@ fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, _ = load(sys.argv[2], "WRITE_SIZE")
 out = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) -- python3 bench.py --steps 1 "
                "--warmup 0 --no-cpu-baseline --no-latency --no-verify; counters are in KB; on gfx950 FETCH_SIZE reads exactly half of a wide coalesced "
-               "read (k_crop_count streams 1,258,291,200 B of input and shows ~614,500 KB), so hbm_bytes = (2*FETCH_SIZE + "
+               "read (k_crop_fused streams the 1,258,291,200 B of input exactly once and shows ~617,000 KB; round 1 calibrated the same way on k_crop_count), so hbm_bytes = (2*FETCH_SIZE + "
                "WRITE_SIZE)*1024",
        "workload": "256 frames x 307200 points, default bench config", "kernels": {}}
 for k in sorted(fetch, key=lambda k: -(2 * fetch[k] + write.get(k, 0))):
