@@ -215,6 +215,7 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
         bool over = false;
         for (int f = 0; f < F; ++f) over = over || c->h_fs[f].crop_overflow != 0;
         if (!over) break;
+        if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: single-pass crop overflowed, redoing the batch in two passes\n");
         kp.enabled = 0;       // rare: redo the crop in two passes (the FrameState init in h_fs was overwritten by the sync)
         for (int f = 0; f < F; ++f) {
             FrameState& s = c->h_fs[f];
@@ -393,6 +394,7 @@ int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
     bool left = false;
     for (int f = 0; f < F; ++f) left = left || (c->h_fs[f].n_o > 0 && !c->h_fs[f].cl_done);
     if (!left) return CD_OK;
+    if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: LDS clustering gave frames up, running the global-memory path\n");
     st = stage_cluster(c, F, p, max_no, true);
     if (st) return st;
     return sync_fs(c, F);

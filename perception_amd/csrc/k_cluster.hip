@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameSta
 //   3. hook, four lanes per occupied cell: first the 13 adjacent forward cells, then (after a barrier, when most
 //      cells already share a root and are skipped on a root compare) the 49 cells two steps away
 //   4. per component: smallest original index and size -> parent / csize as build + hook + flatten produce them
-// A frame the table cannot hold (too many cells, or a cloud wider than 1019 cells) is left to the global-memory path:
+// A frame the table cannot hold (too many cells, or a cloud wider than 1018 cells) is left to the global-memory path:
 // fs.cl_done says which frames are finished.
 #ifdef CD_CLDBG
 // per phase: sum over the workgroups and max over the workgroups of the time thread 0 spent (100 MHz ticks)
@@ -178,7 +178,8 @@ extern "C" int cd_debug_cluster(unsigned long long* out, int reset) {
 constexpr int CL_LDS_CAP = 8192;
 constexpr int CL_SLOTS = 4096;          // cell table (power of two)
 constexpr int CL_MAX_CELLS = 3072;      // load factor <= 3/4
-constexpr int CL_COORD_MAX = 1019;      // 10-bit fields hold coordinate + 2, neighbours reach +-2
+constexpr int CL_COORD_MIN = -1;        // a centroid may round one ulp below the cloud's minimum
+constexpr int CL_COORD_MAX = 1018;      // 10-bit fields hold coordinate + 3, neighbours reach +-2
 constexpr int CL_THREADS = 1024;
 constexpr int CL_PER_THREAD = CL_LDS_CAP / CL_THREADS;
 constexpr int CL_WAVES = CL_THREADS / WAVE;
@@ -293,9 +294,9 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __rest
             pt[k] = P[i];
             int cx, cy, cz;
             cell_of(pt[k], org, inv_cell, cx, cy, cz);
-            bool ok = cx >= 0 && cy >= 0 && cz >= 0 && cx <= CL_COORD_MAX && cy <= CL_COORD_MAX && cz <= CL_COORD_MAX;
+            bool ok = cx >= CL_COORD_MIN && cy >= CL_COORD_MIN && cz >= CL_COORD_MIN && cx <= CL_COORD_MAX && cy <= CL_COORD_MAX && cz <= CL_COORD_MAX;
             if (ok) {
-                const int key = (cx + 2) | ((cy + 2) << 10) | ((cz + 2) << 20);
+                const int key = (cx + 3) | ((cy + 3) << 10) | ((cz + 3) << 20);
                 int h = (int)cl_slot_hash(key);
                 ok = false;
                 for (int probe = 0; probe < CL_SLOTS; ++probe) {
