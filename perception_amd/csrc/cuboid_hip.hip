@@ -238,9 +238,9 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     if (!vin) {   // zero passes (empty frames only): identity permutation is never read
         vin = c->d_val[cur];
     }
+    // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
+    // offset come from a chained scan (state in d_tileA)
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-    LAUNCH(c, launch_voxel_heads_count(c->stream, c->d_key[cur], c->N, F, T, Tc, c->d_fs, c->d_tileA));
-    LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_v), FS_PITCH));
     LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
     if (rounds_out) *rounds_out = 0;
     return CD_OK;

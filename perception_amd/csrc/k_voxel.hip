@@ -205,16 +205,38 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
     }
 }
 
+// Exclusive prefix of `tot` over the tiles 0..tile-1 of one frame by a chained scan ("decoupled look-back"): a tile publishes
+// its own total (flag 1), walks back over its predecessors adding totals until it meets an inclusive prefix (flag 2), and
+// publishes its own inclusive prefix.  state words (zeroed before the launch): flag << 30 | value.  One thread per workgroup.
+// A workgroup only ever waits for workgroups with a smaller id when tiles are numbered in launch order, and the hardware
+// starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup with the smallest id is always
+// running: the waits are finite.  (An atomic ticket would make that independent of the dispatch order, at the price of a
+// dependent memory round trip before the first load; the spin bound turns a wait that does not end into *gave_up = 1.)
+__device__ __forceinline__ int chained_scan(int* state, int tile, int tot, int* gave_up) {
+    unsigned* st = reinterpret_cast<unsigned*>(state);
+    const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;
+    int excl = 0;
+    if (tile > 0) {
+        __hip_atomic_store(st + tile, FLAG_TOTAL | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = tile - 1; q >= 0; --q) {   // q == 0 always carries FLAG_PREFIX: the bound is a guard only
+            unsigned v;
+            int spins = 0;
+            do {
+                v = __hip_atomic_load(st + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1 << 20)) { *gave_up = 1; v = FLAG_PREFIX; }
+            } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0u);
+            excl += (int)(v & VALUE);
+            if (v & FLAG_PREFIX) break;
+        }
+    }
+    __hip_atomic_store(st + tile, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 // ---- single pass: crop + ordered compaction + min/max + absolute voxel coordinates -------
-// One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from a chained scan
-// ("decoupled look-back"): a tile publishes its own total (flag 1), walks back over its predecessors adding totals until it
-// meets an inclusive prefix (flag 2), and publishes its own inclusive prefix.  state words: flag << 30 | value.
+// One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from chained_scan().
 // Workgroup b is tile b / F of frame b % F: the tiles in flight at any time are a few per frame, so a tile's predecessors
-// are usually long done and its look-back ends at the first word.  A workgroup only ever waits for workgroups with a
-// smaller id, and the hardware starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup
-// with the smallest id is always running: the waits are finite.  (An atomic ticket would make that independent of the
-// dispatch order, at the price of a dependent memory round trip before the first load; the spin bound below turns a
-// wait that does not end into the two-pass path instead.)
+// are usually long done and its look-back ends at the first word; a scan that gives up sends the batch to the two-pass path.
 __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ in, size_t stride, int N, int pitch,
                                                       int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
                                                       FrameState* __restrict__ fs, int* __restrict__ state,
@@ -267,24 +289,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k];
-        unsigned* st = reinterpret_cast<unsigned*>(state) + (size_t)f * T;
-        const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;
-        int excl = 0;
-        if (tile > 0) {
-            __hip_atomic_store(st + tile, FLAG_TOTAL | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int q = tile - 1; q >= 0; --q) {   // q == 0 always carries FLAG_PREFIX: the bound is a guard only
-                unsigned v;
-                int spins = 0;
-                do {
-                    v = __hip_atomic_load(st + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    // the ticket order makes this wait finite; should it ever not be, give the batch to the two-pass path
-                    if (++spins > (1 << 20)) { fs[f].crop_overflow = 1; v = FLAG_PREFIX; }
-                } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0u);
-                excl += (int)(v & VALUE);
-                if (v & FLAG_PREFIX) break;
-            }
-        }
-        __hip_atomic_store(st + tile, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int excl = chained_scan(state + (size_t)f * T, tile, tot, &fs[f].crop_overflow);
         s_excl = excl;
         if (tile == Tin - 1) fs[f].n_c = excl + tot;
         if (tot > 0) {
@@ -328,23 +333,6 @@ __device__ __forceinline__ bool is_head(const uint32_t* __restrict__ k, int e, i
     return e < n && (e == 0 || k[e] != k[e - 1]);
 }
 
-__global__ void __launch_bounds__(BLOCK) k_voxel_heads_count(const uint32_t* __restrict__ keys, int N, int T,
-                                                             const FrameState* __restrict__ fs,
-                                                             int* __restrict__ tile_cnt) {
-    __shared__ int s_cnt[WAVES_PER_BLOCK];
-    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = fs[f].n_c;
-    if (tile * TILE >= n) return;
-    const uint32_t* k = keys + (size_t)f * N;
-    const int base = tile * TILE + w * WAVE_SPAN;
-    int cnt = 0;
-#pragma unroll
-    for (int j = 0; j < ITEMS; ++j) cnt += __popcll(__ballot(is_head(k, base + j * WAVE + lane, n)));
-    if (lane == 0) s_cnt[w] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) tile_cnt[(size_t)f * T + tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-}
-
 // One QUAD per voxel.  The 4 lanes fetch 4 consecutive members of the voxel's run at once (indices,
 // then points: members are mostly neighbouring pixels, so the 4 reads usually share a cache line),
 // and every lane of the quad replays the same strictly sequential float32 sum - ascending input
@@ -361,12 +349,16 @@ __device__ __forceinline__ int quad_bcast_i(int v) {
 
 __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ vals,
-                                                          const float4* __restrict__ cpt, int N, int T, int rgb_on,
-                                                          const FrameState* __restrict__ fs,
-                                                          const int* __restrict__ tile_off, float4* __restrict__ vox) {
+                                                          const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
+                                                          FrameState* __restrict__ fs, int* __restrict__ state,
+                                                          float4* __restrict__ vox) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];     // sorted positions of the voxel heads of this tile, in order
-    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int s_out0;
+    // workgroup b is tile b / F of frame b % F (see k_crop_fused): the position of a tile's first voxel in the frame's
+    // output comes from a chained scan of the tiles' head counts, so the heads are found once (no count pass + scan)
+    const int F = gridDim.x / Tact;
+    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -384,6 +376,12 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     __syncthreads();
     int pos = 0, nheads = 0;
     for (int q = 0; q < WAVES_PER_BLOCK; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
+    if (threadIdx.x == 0) {
+        int gave_up = 0;   // cannot happen with in-order dispatch; the result would then be caught by the host (n_v < 0)
+        const int excl = chained_scan(state + (size_t)f * T, tile, nheads, &gave_up);
+        s_out0 = excl;
+        if ((tile + 1) * TILE >= n) fs[f].n_v = gave_up ? -1 : excl + nheads;
+    }
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -391,7 +389,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
         pos += __popcll(bal[j]);
     }
     __syncthreads();
-    const int out0 = tile_off[(size_t)f * T + tile];
+    const int out0 = s_out0;
     const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
     for (int h = quad; h < nheads; h += BLOCK / 4) {
         const int e0 = s_head[h];
@@ -454,13 +452,9 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
     hipLaunchKernelGGL(k_crop_fused, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
                        leaf, kp, fs, state, cpt, keys);
 }
-void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
-                              int* tile_cnt) {
-    hipLaunchKernelGGL(k_voxel_heads_count, dim3(Tact, F), dim3(BLOCK), 0, s, keys, N, T, fs, tile_cnt);
-}
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                           int T, int Tact, int rgb_on, const FrameState* fs, const int* tile_off, float4* vox) {
-    hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact, F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, rgb_on, fs, tile_off, vox);
+                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox) {
+    hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox);
 }
 
 }  // namespace cd

@@ -13,10 +13,8 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
                        int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys);
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
-void launch_voxel_heads_count(hipStream_t s, const uint32_t* keys, int N, int F, int T, int Tact, const FrameState* fs,
-                              int* tile_cnt);
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                           int T, int Tact, int rgb_on, const FrameState* fs, const int* tile_off, float4* vox);
+                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
 
 // k_sort.hip : segmented (per frame) stable LSD radix sort pass on (key, value) pairs
 void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
