@@ -50,6 +50,7 @@ struct FrameState {
     int32_t n_cropped;     // N_c as reported (n_c is zeroed when the frame errors out)
     int32_t cl_done;       // S5: the frame was clustered by k_cluster_lds (0: left to the global-memory kernels)
     int32_t crop_overflow; // single-pass crop: a y cell index did not fit its bit field (the host redoes the batch in two passes)
+    int32_t scan_stalled;  // a chained scan gave up waiting for a predecessor tile (reported as CD_ERR_DEVICE)
 };
 
 struct CropLimits {        // double limits folded to equivalent float compares (exact)
@@ -189,6 +190,34 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, float by, float bz) {
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+}
+// Exclusive prefix of `tot` over the tiles 0..tile-1 of one frame by a chained scan ("decoupled look-back"): a tile publishes
+// its own total (flag 1), walks back over its predecessors adding totals until it meets an inclusive prefix (flag 2), and
+// publishes its own inclusive prefix.  state words (zeroed before the launch): flag << 30 | value; tile q's word is
+// state[q * stride] (one thread per workgroup for a scalar scan, one thread per bin for the radix scatter).
+// A workgroup only ever waits for workgroups with a smaller id when tiles are numbered in launch order, and the hardware
+// starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup with the smallest id is always
+// running: the waits are finite.  (An atomic ticket would make that independent of the dispatch order, at the price of a
+// dependent memory round trip before the first load; the spin bound turns a wait that does not end into *gave_up = 1.)
+__device__ __forceinline__ int chained_scan(int* state, int stride, int tile, int tot, int* gave_up) {
+    unsigned* st = reinterpret_cast<unsigned*>(state);
+    const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;
+    int excl = 0;
+    if (tile > 0) {
+        __hip_atomic_store(st + (size_t)tile * stride, FLAG_TOTAL | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = tile - 1; q >= 0; --q) {   // q == 0 always carries FLAG_PREFIX: the bound is a guard only
+            unsigned v;
+            int spins = 0;
+            do {
+                v = __hip_atomic_load(st + (size_t)q * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1 << 20)) { *gave_up = 1; v = FLAG_PREFIX; }
+            } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0u);
+            excl += (int)(v & VALUE);
+            if (v & FLAG_PREFIX) break;
+        }
+    }
+    __hip_atomic_store(st + (size_t)tile * stride, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
 }
 // canonical plane distance: |(a*x + b*y) + (c*z + d)|
 __device__ __forceinline__ float plane_dist(float a, float b, float c, float d, float x, float y, float z) {

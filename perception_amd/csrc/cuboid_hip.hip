@@ -35,7 +35,8 @@ struct cd_context {
     bool crop_two_pass = false;   // CUBOID_CROP_TWO_PASS=1: always the two-pass crop
     // point buffers (float4 = x,y,z,rgb bits)
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
-    uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_hist = nullptr;
+    uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_ghist = nullptr;
+    int* d_sstate = nullptr;   // chained-scan state of the radix passes, [pass][F][tiles][256]
     // RANSAC
     int* d_rnd = nullptr;
     float4* d_models = nullptr;
@@ -156,6 +157,8 @@ int ensure_clusters(cd_context* c, int ncl, long long points) {
 int sync_fs(cd_context* c, int F) {
     HIPCHK(c, hipMemcpyAsync(c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int f = 0; f < F; ++f)
+        if (c->h_fs[f].scan_stalled) return fail(c, CD_ERR_DEVICE, "a chained scan stalled (workgroups of a grid were not started in id order)");
     return CD_OK;
 }
 
@@ -226,18 +229,11 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     int max_nc = 0, max_bits = 0;
     for (int f = 0; f < F; ++f) { max_nc = std::max(max_nc, c->h_fs[f].n_c); max_bits = std::max(max_bits, c->h_fs[f].key_bits); }
     const int Tc = std::max(1, (max_nc + TILE - 1) / TILE);
-    const int Ts = (c->N + SORT_TILE - 1) / SORT_TILE, Tsc = std::max(1, (max_nc + SORT_TILE - 1) / SORT_TILE);
+    const int Tsc = std::max(1, (max_nc + SORT_TILE - 1) / SORT_TILE);
+    const int npass = (max_bits + RADIX_BITS - 1) / RADIX_BITS;
     int cur = 0;
-    const uint32_t* vin = nullptr;
-    for (int shift = 0; shift < max_bits; shift += RADIX_BITS) {
-        LAUNCH(c, launch_radix_pass(c->stream, c->d_key[cur], vin, c->d_key[cur ^ 1], c->d_val[cur ^ 1], c->N, F, Ts, Tsc, shift, c->d_fs, c->d_hist, kp));
-        kp.enabled = 0;       // later passes read voxel indices
-        cur ^= 1;
-        vin = c->d_val[cur];
-    }
-    if (!vin) {   // zero passes (empty frames only): identity permutation is never read
-        vin = c->d_val[cur];
-    }
+    LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp));
+    const uint32_t* vin = c->d_val[cur];   // zero passes (empty frames only): the permutation is never read
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
@@ -867,7 +863,7 @@ void cd_destroy(cd_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
-                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_hist, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
+                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
@@ -900,7 +896,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_cpt, FN) == hipSuccess && dalloc(&c->d_vox, FN) == hipSuccess && dalloc(&c->d_obj, FN) == hipSuccess;
     ok = ok && dalloc(&c->d_src0, FN) == hipSuccess && dalloc(&c->d_src, FN) == hipSuccess;
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
-    ok = ok && dalloc(&c->d_hist, F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
+    ok = ok && dalloc(&c->d_ghist, F * SORT_MAX_PASSES_HOST * RADIX) == hipSuccess;
+    ok = ok && dalloc(&c->d_sstate, (size_t)SORT_MAX_PASSES_HOST * F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
     ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess && halloc(&c->h_models, F * MAX_HYP) == hipSuccess;

@@ -1,17 +1,18 @@
 // k_sort.hip - segmented stable LSD radix sort (8-bit digits), one segment per frame.
 //
 // VoxelGrid sorts the cropped points by voxel index (pcl::VoxelGrid::applyFilter uses
-// std::sort on (idx, point) pairs; rule C2 makes it stable).  One pass = three kernels over
-// ordered tiles of 2048 pairs:
-//   hist    : per-tile digit histogram (LDS atomics)            -> hist[f][tile][digit]  (digit fastest: every
-//             access of the three kernels to it is coalesced)
-//   scan    : per frame, exclusive scan in (digit, tile) order  -> global base of every bin
-//   scatter : stable rank of each pair inside its tile with wave ballots ("match-any" over
-//             the 8 digit bits, 64-wide), then one scattered store per pair.
+// std::sort on (idx, point) pairs; rule C2 makes it stable).  Single-histogram ("onesweep") organisation:
+//   ghist   : ONE pass over the keys builds the per-frame digit histograms of ALL passes (the histogram of a digit does
+//             not depend on the order of the elements)
+//   scatter : per pass and ordered tile of 8192 pairs - stable rank of each pair inside its tile with wave ballots
+//             ("match-any" over the 8 digit bits, 64-wide); the tile's bin counts go through a chained scan over the
+//             frame's tiles (one thread per bin, common.hpp chained_scan) and give, with the exclusive scan of the
+//             frame's digit histogram, where the tile's part of every bin starts; the tile is put in bin order in LDS and
+//             written out as contiguous runs.
 // Element order inside a tile is (wave, row, lane), so per-wave running bin counts kept in
 // LDS plus a cross-wave prefix give the stable position.  A sort tile is 8192 pairs (1024 threads x 8 rows): with 256
-// bins a tile sends ~32 consecutive pairs to each bin, so the scattered 4-byte stores fill whole 128-byte lines (with
-// 2048-pair tiles the scatter wrote twice the bytes it stored).
+// bins a tile sends ~32 consecutive pairs to each bin.  (Rounds 1-2 ran a per-tile histogram kernel and a scan kernel before
+// every scatter: three reads of the keys more per sort.)
 #include "kernels.hpp"
 
 namespace cd {
@@ -38,82 +39,67 @@ __device__ __forceinline__ uint32_t voxel_key(uint32_t a, const KeyPack& kp, con
     return (uint32_t)(i0 + i1 * g.d0 + i2 * g.d01);
 }
 
-__global__ void __launch_bounds__(SORT_BLOCK) k_radix_hist(const uint32_t* __restrict__ kin, int N, int T, int shift,
-                                                           const FrameState* __restrict__ fs, uint32_t* __restrict__ hist,
-                                                           KeyPack kp) {
-    __shared__ uint32_t s_h[RADIX];
-    const int f = blockIdx.y, tile = blockIdx.x;
+constexpr int SORT_MAX_PASSES = 4;
+constexpr int GHIST_TILES = 4;   // sort tiles per workgroup of the histogram kernel (fewer global flushes)
+
+// ghist[f][pass][digit] += occurrences, for every pass at once.  Neighbouring elements mostly carry the same digit
+// (neighbouring pixels): only the first lane of a run of equal digits adds, the run length at once - the LDS serialises
+// lanes that add to one address, which is the whole cost of a histogram.
+__global__ void __launch_bounds__(SORT_BLOCK) k_radix_ghist(const uint32_t* __restrict__ kin, int N, int npass,
+                                                            const FrameState* __restrict__ fs, uint32_t* __restrict__ ghist,
+                                                            KeyPack kp) {
+    __shared__ uint32_t s_h[SORT_MAX_PASSES][RADIX];
+    const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
-    if (tile * SORT_TILE >= n) return;
-    if (threadIdx.x < RADIX) s_h[threadIdx.x] = 0;
+    const int e0 = blockIdx.x * GHIST_TILES * SORT_TILE;
+    if (e0 >= n) return;
+    for (int q = threadIdx.x; q < SORT_MAX_PASSES * RADIX; q += SORT_BLOCK) (&s_h[0][0])[q] = 0;
     __syncthreads();
     const uint32_t* k = kin + (size_t)f * N;
-    const int base = tile * SORT_TILE + (threadIdx.x >> 6) * WAVE_SPAN + (threadIdx.x & 63);
     const KeyGrid g = key_grid(fs[f]);
-    const int lane = threadIdx.x & 63;
+    for (int t = 0; t < GHIST_TILES; ++t) {
+        const int base = e0 + t * SORT_TILE + (threadIdx.x >> 6) * WAVE_SPAN + lane;
+        if (e0 + t * SORT_TILE >= n) break;
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        const int e = base + j * WAVE;
-        // Neighbouring elements mostly carry the same digit (neighbouring pixels, or an input ordered by the lower digits):
-        // only the first lane of a run of equal digits adds, the run length at once - the LDS serialises lanes that add to
-        // one address, which was the whole cost of this kernel.
-        uint32_t d = 0xffffffffu;   // past the end: a run of its own that adds nothing
-        if (e < n) {
-            const uint32_t key = kp.enabled ? voxel_key(k[e], kp, g) : k[e];
-            d = (key >> shift) & (RADIX - 1);
+        for (int j = 0; j < ITEMS; ++j) {
+            const int e = base + j * WAVE;
+            const bool valid = e < n;
+            uint32_t key = 0;
+            if (valid) key = kp.enabled ? voxel_key(k[e], kp, g) : k[e];
+            for (int p = 0; p < npass; ++p) {
+                const uint32_t d = valid ? ((key >> (p * RADIX_BITS)) & (RADIX - 1)) : 0xffffffffu;   // past the end: own run
+                const uint32_t prev = (uint32_t)__shfl_up((int)d, 1, 64);
+                const uint64_t heads = __ballot(lane == 0 || d != prev);
+                const uint64_t above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
+                const int next = above ? __ffsll((long long)above) - 1 : 64;
+                if (((heads >> lane) & 1ull) && valid) atomicAdd(&s_h[p][d], (uint32_t)(next - lane));
+            }
         }
-        const uint32_t prev = (uint32_t)__shfl_up((int)d, 1, 64);
-        const uint64_t heads = __ballot(lane == 0 || d != prev);
-        const uint64_t above = lane == 63 ? 0ull : heads & ~((2ull << lane) - 1ull);
-        const int next = above ? __ffsll((long long)above) - 1 : 64;
-        if (((heads >> lane) & 1ull) && e < n) atomicAdd(&s_h[d], (uint32_t)(next - lane));
     }
     __syncthreads();
-    if (threadIdx.x < RADIX) hist[((size_t)f * T + tile) * RADIX + threadIdx.x] = s_h[threadIdx.x];
-}
-
-// one block per frame; thread d owns digit d's row of Tact tiles
-__global__ void __launch_bounds__(BLOCK) k_radix_scan(int T, const FrameState* __restrict__ fs, uint32_t* __restrict__ hist) {
-    __shared__ uint32_t s_w[WAVES_PER_BLOCK];
-    const int f = blockIdx.x, d = threadIdx.x, w = d >> 6, lane = d & 63;
-    const int n = fs[f].n_c;
-    if (n <= 0) return;
-    const int tact = (n + SORT_TILE - 1) / SORT_TILE;
-    uint32_t* col = hist + (size_t)f * T * RADIX + d;
-    uint32_t sum = 0;
-    for (int t = 0; t < tact; ++t) {
-        const uint32_t v = col[(size_t)t * RADIX];
-        col[(size_t)t * RADIX] = sum;
-        sum += v;
+    for (int q = threadIdx.x; q < npass * RADIX; q += SORT_BLOCK) {
+        const uint32_t c = (&s_h[0][0])[q];
+        if (c) atomicAdd(&ghist[(size_t)f * SORT_MAX_PASSES * RADIX + q], c);
     }
-    uint32_t inc = sum;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t u = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += u;
-    }
-    if (lane == 63) s_w[w] = inc;
-    __syncthreads();
-    uint32_t base = inc - sum;
-    for (int q = 0; q < w; ++q) base += s_w[q];
-    for (int t = 0; t < tact; ++t) col[(size_t)t * RADIX] += base;
 }
 
 __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
-                                                         int T, int shift, const FrameState* __restrict__ fs,
-                                                         const uint32_t* __restrict__ hist, KeyPack kp) {
+                                                         int T, int Tact, int pass, FrameState* __restrict__ fs,
+                                                         const uint32_t* __restrict__ ghist, int* __restrict__ state,
+                                                         KeyPack kp) {
     __shared__ unsigned short s_wh[SORT_WAVES][RADIX];   // per-wave bin counts, then the wave's offset inside the bin
     __shared__ uint32_t s_goff[RADIX];                   // where the tile's part of each bin starts in the frame
     __shared__ uint32_t s_bstart[RADIX];                 // where each bin starts inside the tile
     __shared__ uint32_t s_k[SORT_TILE], s_v[SORT_TILE];  // the tile, ordered by bin (64 KiB)
-    __shared__ uint32_t s_ws[RADIX / WAVE];
-    const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ uint32_t s_ws[RADIX / WAVE], s_gs[RADIX / WAVE];
+    // workgroup b is tile b / F of frame b % F (see k_crop_fused): a tile's predecessors in the chained scan are long done
+    const int F = gridDim.x / Tact, shift = pass * RADIX_BITS;
+    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
     for (int q = threadIdx.x; q < SORT_WAVES * RADIX; q += SORT_BLOCK) (&s_wh[0][0])[q] = 0;
-    if (threadIdx.x < RADIX) s_goff[threadIdx.x] = hist[((size_t)f * T + tile) * RADIX + threadIdx.x];
     __syncthreads();
     const int base = tile * SORT_TILE + w * WAVE_SPAN + lane;
     const uint64_t lt = lanemask_lt();
@@ -152,20 +138,26 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
             s_wh[q][d] = (unsigned short)run;
             run += c;
         }
-        uint32_t inc = run;
+        // where the frame's bin d starts: exclusive scan of the frame's digit histogram ...
+        const uint32_t tot = ghist[((size_t)f * SORT_MAX_PASSES + pass) * RADIX + d];
+        uint32_t inc = run, ginc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t u = __shfl_up(inc, o, 64);
-            if (lane >= o) inc += u;
+            const uint32_t u = __shfl_up(inc, o, 64), gu = __shfl_up(ginc, o, 64);
+            if (lane >= o) { inc += u; ginc += gu; }
         }
-        if (lane == 63) s_ws[w] = inc;
-        s_bstart[d] = inc - run;   // completed below with the totals of the lower waves
+        if (lane == 63) { s_ws[w] = inc; s_gs[w] = ginc; }
+        s_bstart[d] = inc - run;   // both completed below with the totals of the lower waves
+        // ... plus what the tiles before this one put into bin d (chained scan over the frame's tiles, one thread per bin)
+        const int before = chained_scan(state + (size_t)f * T * RADIX + d, RADIX, tile, (int)run, &fs[f].scan_stalled);
+        s_goff[d] = ginc - tot + (uint32_t)before;
     }
     __syncthreads();
     if (threadIdx.x < RADIX) {
-        uint32_t add = 0;
-        for (int q = 0; q < w; ++q) add += s_ws[q];
+        uint32_t add = 0, gadd = 0;
+        for (int q = 0; q < w; ++q) { add += s_ws[q]; gadd += s_gs[q]; }
         s_bstart[threadIdx.x] += add;
+        s_goff[threadIdx.x] += gadd;
     }
     __syncthreads();
     // the tile in bin order, staged in LDS: the global stores below are then contiguous runs (one run per bin) instead of
@@ -195,13 +187,25 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     }
 }
 
-// T = sort tiles per frame the histogram is laid out for, Tact = sort tiles that hold data (max over the frames)
-// kp.enabled: kin holds the absolute coordinate fields of k_crop_fused (first pass only); kout gets voxel indices
-void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
-                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist, KeyPack kp) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, N, T, shift, fs, hist, kp);
-    hipLaunchKernelGGL(k_radix_scan, dim3(F), dim3(BLOCK), 0, s, T, fs, hist);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(Tact, F), dim3(SORT_BLOCK), 0, s, kin, vin, kout, vout, N, T, shift, fs, hist, kp);
+// All passes of one sort.  Tact = sort tiles that hold data (max over the frames).  ghist [F][SORT_MAX_PASSES][RADIX] and
+// state [npass][F][Tact][RADIX] are zeroed here.  kp.enabled: key[0] holds the
+// absolute coordinate fields of k_crop_fused; the first pass writes voxel indices.  Returns the index of the buffers
+// that hold the sorted keys / the permutation.
+int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
+                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp) {
+    if (npass <= 0) return 0;
+    (void)hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s);
+    (void)hipMemsetAsync(state, 0, sizeof(int) * (size_t)npass * F * Tact * RADIX, s);
+    const int G = (Tact + GHIST_TILES - 1) / GHIST_TILES;
+    hipLaunchKernelGGL(k_radix_ghist, dim3(G, F), dim3(SORT_BLOCK), 0, s, key[0], N, npass, fs, ghist, kp);
+    int cur = 0;
+    for (int pass = 0; pass < npass; ++pass) {
+        hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], pass ? val[cur] : nullptr, key[cur ^ 1],
+                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp);
+        kp.enabled = 0;   // later passes read voxel indices
+        cur ^= 1;
+    }
+    return cur;
 }
 
 }  // namespace cd

@@ -205,34 +205,6 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
     }
 }
 
-// Exclusive prefix of `tot` over the tiles 0..tile-1 of one frame by a chained scan ("decoupled look-back"): a tile publishes
-// its own total (flag 1), walks back over its predecessors adding totals until it meets an inclusive prefix (flag 2), and
-// publishes its own inclusive prefix.  state words (zeroed before the launch): flag << 30 | value.  One thread per workgroup.
-// A workgroup only ever waits for workgroups with a smaller id when tiles are numbered in launch order, and the hardware
-// starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup with the smallest id is always
-// running: the waits are finite.  (An atomic ticket would make that independent of the dispatch order, at the price of a
-// dependent memory round trip before the first load; the spin bound turns a wait that does not end into *gave_up = 1.)
-__device__ __forceinline__ int chained_scan(int* state, int tile, int tot, int* gave_up) {
-    unsigned* st = reinterpret_cast<unsigned*>(state);
-    const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;
-    int excl = 0;
-    if (tile > 0) {
-        __hip_atomic_store(st + tile, FLAG_TOTAL | (unsigned)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        for (int q = tile - 1; q >= 0; --q) {   // q == 0 always carries FLAG_PREFIX: the bound is a guard only
-            unsigned v;
-            int spins = 0;
-            do {
-                v = __hip_atomic_load(st + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (++spins > (1 << 20)) { *gave_up = 1; v = FLAG_PREFIX; }
-            } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0u);
-            excl += (int)(v & VALUE);
-            if (v & FLAG_PREFIX) break;
-        }
-    }
-    __hip_atomic_store(st + tile, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return excl;
-}
-
 // ---- single pass: crop + ordered compaction + min/max + absolute voxel coordinates -------
 // One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from chained_scan().
 // Workgroup b is tile b / F of frame b % F: the tiles in flight at any time are a few per frame, so a tile's predecessors
@@ -289,7 +261,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
     if (threadIdx.x == 0) {
         int tot = 0;
         for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k];
-        const int excl = chained_scan(state + (size_t)f * T, tile, tot, &fs[f].crop_overflow);
+        const int excl = chained_scan(state + (size_t)f * T, 1, tile, tot, &fs[f].crop_overflow);
         s_excl = excl;
         if (tile == Tin - 1) fs[f].n_c = excl + tot;
         if (tot > 0) {
@@ -377,10 +349,9 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     int pos = 0, nheads = 0;
     for (int q = 0; q < WAVES_PER_BLOCK; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
     if (threadIdx.x == 0) {
-        int gave_up = 0;   // cannot happen with in-order dispatch; the result would then be caught by the host (n_v < 0)
-        const int excl = chained_scan(state + (size_t)f * T, tile, nheads, &gave_up);
+        const int excl = chained_scan(state + (size_t)f * T, 1, tile, nheads, &fs[f].scan_stalled);
         s_out0 = excl;
-        if ((tile + 1) * TILE >= n) fs[f].n_v = gave_up ? -1 : excl + nheads;
+        if ((tile + 1) * TILE >= n) fs[f].n_v = excl + nheads;
     }
     const uint64_t lt = lanemask_lt();
 #pragma unroll

@@ -16,9 +16,10 @@ void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, in
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
 
-// k_sort.hip : segmented (per frame) stable LSD radix sort pass on (key, value) pairs
-void launch_radix_pass(hipStream_t s, const uint32_t* kin, const uint32_t* vin, uint32_t* kout, uint32_t* vout, int N,
-                       int F, int T, int Tact, int shift, const FrameState* fs, uint32_t* hist, KeyPack kp);
+// k_sort.hip : segmented (per frame) stable LSD radix sort of (key, value) pairs, all passes
+constexpr int SORT_MAX_PASSES_HOST = 4;
+int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
+                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp);
 
 // k_plane.hip
 void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,
