@@ -209,6 +209,11 @@ int cd_process_batch(cd_context* ctx, const void* frames, size_t stride_bytes,
                      int points_per_frame, int n_frames, const cd_params* prm,
                      cd_frame_result* results, int32_t* plane_inliers, int32_t* labels);
 
+/* One frame: the body of the reference's callback / service handler (gps.cpp:43-112 followed by icp.cpp:150-182, or
+ * opd.cpp:270-441) as one call - cd_process_batch with n_frames = 1 and `n` points. */
+int cd_process_frame(cd_context* ctx, const void* points, size_t stride_bytes, int n, const cd_params* prm,
+                     cd_frame_result* result, int32_t* plane_inliers, int32_t* labels);
+
 /* opd.cpp:376-413 runs ICP on EVERY cluster of the frame and picks among all of them (:416-423).  The fixed-size record
  * carries the CD_MAX_CLUSTERS_PER_FRAME largest; when a frame has more (flags & CD_FRAME_MORE_CLUSTERS) the others - all of
  * them were registered as well - are read here.  Copies the results of clusters [first, first + capacity) of `frame`

@@ -29,7 +29,7 @@ LIB_PATH = os.environ.get("CUBOID_HIP_LIB") or os.path.join(os.path.dirname(os.p
 EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
     "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
-    "cd_process_batch", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
+    "cd_process_batch", "cd_process_frame", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing",
 ]
 
@@ -160,6 +160,7 @@ def load_library(path=None):
                            C.POINTER(CdClusterResult), vp]
     for f in (lib.cd_process_batch, lib.cd_process_batch_device):
         f.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(CdParams), vp, vp, vp]
+    lib.cd_process_frame.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp, vp]
     lib.cd_get_cluster_results.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.POINTER(CdClusterResult), ip]
     lib.cd_pose_to_position_quaternion.argtypes = [C.POINTER(C.c_double)] * 3
     lib.cd_pose_to_position_quaternion.restype = None
@@ -282,6 +283,17 @@ class Context:
         lb = np.empty((F, N), np.int32) if want_indices else None
         self._check(self.lib.cd_process_batch(self.h, _ptr(f), Cc * 4, N, F, C.byref(prm),
                                               C.cast(res, C.c_void_p), _ptr(pi), _ptr(lb)))
+        return res, pi, lb
+
+    def process_frame(self, points, prm, want_indices=False):
+        """One frame (N, C>=3) float32: the reference's callback body as one call.  Returns (result, plane_inliers, labels)."""
+        f = np.ascontiguousarray(points, dtype=np.float32)
+        assert f.ndim == 2
+        N, Cc = f.shape
+        res = CdFrameResult()
+        pi = np.empty(N, np.int32) if want_indices else None
+        lb = np.empty(N, np.int32) if want_indices else None
+        self._check(self.lib.cd_process_frame(self.h, _ptr(f), Cc * 4, N, C.byref(prm), C.byref(res), _ptr(pi), _ptr(lb)))
         return res, pi, lb
 
     def process_batch_device(self, dev_ptr, stride_bytes, points_per_frame, n_frames, prm,

@@ -1438,6 +1438,11 @@ int cd_process_batch(cd_context* c, const void* frames, size_t stride, int point
     return process_batch_impl(c, c->d_in, stride, points_per_frame, n_frames, p, results, plane_inliers, labels);
 }
 
+int cd_process_frame(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, cd_frame_result* result,
+                     int32_t* plane_inliers, int32_t* labels) {
+    return cd_process_batch(c, points, stride, n, 1, p, result, plane_inliers, labels);
+}
+
 int cd_get_cluster_results(const cd_context* c, int frame, int first, int capacity, cd_cluster_result* out, int* out_total) {
     if (!c) return CD_ERR_INVALID_ARG;
     if (out_total) *out_total = 0;

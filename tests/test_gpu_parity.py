@@ -266,6 +266,15 @@ def test_icp_large_template_and_real_cluster(ctx, O):
     _same_cluster(res, r0)
 
 
+def test_process_frame_is_a_batch_of_one(ctx, frames4):
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    r1, pi1, lb1 = ctx.process_frame(frames4[1], prm, want_indices=True)
+    rb, pib, lbb = ctx.process_batch(frames4[1][None], prm, want_indices=True)
+    assert bytes(r1) == bytes(rb[0]) and np.array_equal(pi1, pib[0]) and np.array_equal(lb1, lbb[0])
+    assert r1.n_clusters >= 1 and r1.status == 0
+
+
 def test_batch_matches_oracle_and_goldens(ctx, O, template, frames4):
     prm = capi.default_params()
     prm.rgb_offset = 12
