@@ -56,7 +56,8 @@ struct cd_context {
     unsigned short* d_tcell = nullptr;                            // cell start tables, ICP_CELL_STRIDE entries per slot
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
     float* d_d2 = nullptr;                                        // its squared distance
-    int* d_queue = nullptr;                                       // ICP work queue head
+    int* d_queue = nullptr;                                       // ICP work queue heads (one per template group)
+    int* d_wgtab = nullptr;                                       // k_icp_pipe: {first item, end item, queue} per workgroup
     int n_cu = 256;
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
@@ -407,11 +408,37 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     for (int k = 0; k < ncl; ++k) qtot += c->h_cl[k].n;
     int qslice = (int)((qtot / 512 + 15) / 16 * 16);
     qslice = std::max(64, std::min(ICP_QSLICE, qslice));
+    // Template groups: runs of clusters that share a template (one run per template when every cluster is matched against
+    // every template).  With several templates in the batch, the groups whose template is LDS-resident and gridded go through
+    // ONE k_icp_pipe launch (each group gets a share of the workgroups and its own queue) when there are enough of them to
+    // fill half the chip; the other clusters take the sliced driver below.
+    struct TplGroup { int beg, end, live; bool pipe; long long pts; };
+    std::vector<TplGroup> groups;
+    for (int k = 0; k < ncl; ++k) {
+        const IcpCluster& cl = c->h_cl[k];
+        if (groups.empty() || c->h_cl[groups.back().beg].tpl_off != cl.tpl_off || c->h_cl[groups.back().beg].tpl_m != cl.tpl_m)
+            groups.push_back(TplGroup{k, k, 0, cl.tpl_m > 0 && cl.tpl_m <= ICP_TPL_LDS && c->tpl_gridded[cl.slot] != 0, 0});
+        TplGroup& g = groups.back();
+        g.end = k + 1;
+        if (cl.n >= 3) { g.live += 1; g.pts += cl.n; }
+    }
+    int n_grouped = 0;
+    for (const TplGroup& g : groups) if (g.pipe) n_grouped += g.live;
+    const bool grouped_pipe = groups.size() > 1 && groups.size() <= 16 && n_grouped > 0 &&
+                              (c->icp_mode == 3 || (c->icp_mode == 0 && n_grouped >= c->n_cu / 2));
+    if (std::getenv("CUBOID_DEBUG")) {
+        std::fprintf(stderr, "cuboid_hip: stage_icp %d clusters, %zu template groups, %d in pipe groups, grouped_pipe %d:", ncl, groups.size(), n_grouped, (int)grouped_pipe);
+        for (const TplGroup& g : groups) std::fprintf(stderr, " [%d,%d) m=%d pipe=%d live=%d", g.beg, g.end, c->h_cl[g.beg].tpl_m, (int)g.pipe, g.live);
+        std::fprintf(stderr, "\n");
+    }
+    std::vector<char> in_pipe((size_t)ncl, 0);
+    if (grouped_pipe)
+        for (const TplGroup& g : groups) if (g.pipe) for (int k = g.beg; k < g.end; ++k) in_pipe[(size_t)k] = 1;
     int nwork = 0;
     for (int k = 0; k < ncl; ++k) {
         IcpCluster& cl = c->h_cl[k];
         cl.tile0 = nwork;
-        const int tiles = cl.n >= 3 && cl.tpl_m > 0 ? (cl.n + qslice - 1) / qslice : 0;
+        const int tiles = cl.n >= 3 && cl.tpl_m > 0 && !in_pipe[(size_t)k] ? (cl.n + qslice - 1) / qslice : 0;
         if (nwork + tiles > c->work_cap) return fail(c, CD_ERR_CAPACITY, "ICP work list overflow");
         for (int t = 0; t < tiles; ++t) c->h_work[nwork++] = IcpWork{k, t};
         for (int s = 0; s < 2; ++s) {
@@ -445,7 +472,52 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     for (int k = 1; k < ncl && pipe_ok; ++k) pipe_ok = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
     // (auto mode: only the pipelined kernel beats the sliced driver; with mixed or non-resident templates k_icp_cluster's
     // barrier per iteration costs more than it saves, so those batches stay sliced unless the mode is forced)
-    const bool whole_cluster = c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2 && pipe_ok);
+    const bool whole_cluster = !grouped_pipe && (c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2 && pipe_ok));
+    if (grouped_pipe) {
+        // items of `order`: the pipe groups one after the other, each largest cluster first
+        const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
+        std::vector<int> tab;
+        long long pts_all = 0;
+        int npg = 0;
+        for (const TplGroup& g : groups) if (g.pipe && g.live > 0) { pts_all += g.pts; ++npg; }
+        int no = 0, gq = 0, n_wg = 0;
+        for (const TplGroup& g : groups) {
+            if (!g.pipe || g.live == 0) continue;
+            const int b = no;
+            for (int k = g.beg; k < g.end; ++k) if (c->h_cl[k].n >= 3) c->h_order[no++] = k;
+            std::stable_sort(c->h_order + b, c->h_order + no, [&](int x, int y) { return c->h_cl[x].n > c->h_cl[y].n; });
+            // workgroups in proportion to the group's points, at least one, no more than it has clusters
+            int share = (int)((long long)wg_cap * g.pts / std::max(pts_all, 1ll));
+            share = std::max(1, std::min(share, std::min(g.live, wg_cap - n_wg - (npg - 1 - gq))));
+            for (int w = 0; w < share; ++w) { tab.push_back(b); tab.push_back(no); tab.push_back(gq); }
+            n_wg += share;
+            ++gq;
+        }
+        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
+        LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+                        c->d_queue, n_wg, c->d_wgtab, ip));
+        c->timing.icp_kernel_launches = 1;
+        // `tab` must outlive the copy: the sliced part below (or the read-back) synchronises the stream before it goes away
+        if (nwork == 0) {
+            HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms1 = 0.f;
+            hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
+            c->timing.icp_kernel_ms = ms1;
+            if (pair_tests) {
+                long long tot = 0;
+                for (int k = 0; k < ncl; ++k)
+                    if (c->h_st[2 * k].status == CD_OK) tot += (long long)c->h_cl[k].n * c->h_cl[k].tpl_m * (c->h_st[2 * k].iters + 1);
+                *pair_tests = tot;
+            }
+            return CD_OK;
+        }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     if (whole_cluster) {
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
@@ -454,7 +526,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                            c->d_queue, wg_cap, ip));
+                            c->d_queue, std::min(ncl, wg_cap), nullptr, ip));
         else
             LAUNCH(c, launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                                c->d_queue, wg_cap, ip));
@@ -865,7 +937,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     if (c->d_koffx) hipFree(c->d_koffx);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
@@ -914,7 +986,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_kdmap, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tplk, (size_t)c->tpl_cap) == hipSuccess && dalloc(&c->d_tlok, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thik, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
-    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)4) == hipSuccess;
+    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)16) == hipSuccess && dalloc(&c->d_wgtab, (size_t)3 * 1024) == hipSuccess;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;

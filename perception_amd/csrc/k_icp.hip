@@ -1039,10 +1039,11 @@ __device__ __noinline__ int pipe_solve(PipeSlot* sl, const IcpParams& prm) {
 }
 
 // next cluster from the global queue into the slot (lane 0 of the finishing wave)
-__device__ __forceinline__ void pipe_refill(PipeSlot* sl, int ncl, const int* order, const IcpCluster* cl, const IcpState* st, int* queue) {
+// (items [gbeg, gend) of `order`: the clusters that share the workgroup's template)
+__device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, const int* order, const IcpCluster* cl, const IcpState* st, int* queue) {
     for (;;) {
-        const int item = atomicAdd(queue, 1);
-        if (item >= ncl) { sl->phase = PH_EXHAUSTED; return; }
+        const int item = gbeg + atomicAdd(queue, 1);
+        if (item >= gend) { sl->phase = PH_EXHAUSTED; return; }
         const int k = order[item];
         if (st[2 * (size_t)k].done) continue;            // host pre-marked (too few points / no template)
         const IcpCluster c = cl[k];
@@ -1061,15 +1062,21 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                                                            const unsigned short* __restrict__ kdmap,
                                                            const IcpGrid* __restrict__ grids,
                                                            const unsigned short* __restrict__ tcell, float4* src,
-                                                           const float4* __restrict__ src0, int* nn, int* queue, IcpParams prm) {
+                                                           const float4* __restrict__ src0, int* nn, int* queue,
+                                                           const int* __restrict__ wgtab, IcpParams prm) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // every cluster of one launch uses the same (LDS-resident, gridded) template - the host guarantees it
-    const IcpCluster c0 = cl[order[0]];
+    // A workgroup keeps ONE (LDS-resident, gridded) template for its whole life.  With several templates in a launch
+    // (every cluster against every template, opd flavour with template_slot = -1) the host groups the clusters by template,
+    // gives every group a share of the workgroups and its own queue: wgtab[3 b] = {first item, end item, queue} of
+    // workgroup b; without a table all clusters share one template and one queue.
+    int gbeg = 0, gend = ncl;
+    if (wgtab) { gbeg = wgtab[3 * blockIdx.x]; gend = wgtab[3 * blockIdx.x + 1]; queue += wgtab[3 * blockIdx.x + 2]; }
+    const IcpCluster c0 = cl[order[gbeg]];
     const IcpGrid g = grids[c0.slot];
     const float4* tp = tpl + c0.tpl_off;
     const int tpl_m = c0.tpl_m;
@@ -1098,7 +1105,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
             sl->arrived = 0; sl->epoch = 0; sl->phase = PH_FILL; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
         }
         // slot 0 starts with a cluster; slot 1 is filled by its first finisher, after every workgroup took its first
-        pipe_refill(&s_slot[0], ncl, order, cl, st, queue);
+        pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue);
     }
     __syncthreads();
 #ifdef CD_TIMERS
@@ -1241,7 +1248,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                             st[2 * (size_t)sl->k + 1] = sl->so;
                             accf[sl->k] = sl->acc[0];
                         }
-                        pipe_refill(sl, ncl, order, cl, st, queue);
+                        pipe_refill(sl, gbeg, gend, order, cl, st, queue);
                     }
                     for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
                     sl->arrived = 0;
@@ -1340,10 +1347,10 @@ void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpClust
 void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
                      const float4* tpl, const float4* tlo, const float4* thi, const unsigned short* kdmap, const IcpGrid* grids,
                      const unsigned short* tcell, float4* src, const float4* src0, int* nn,
-                     int* queue, int n_cu, IcpParams prm) {
-    if (ncl <= 0) return;
-    hipLaunchKernelGGL(k_icp_pipe, dim3(ncl < n_cu ? ncl : n_cu), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
-                       kdmap, grids, tcell, src, src0, nn, queue, prm);
+                     int* queue, int n_wg, const int* wgtab, IcpParams prm) {
+    if (ncl <= 0 || n_wg <= 0) return;
+    hipLaunchKernelGGL(k_icp_pipe, dim3(n_wg), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
+                       kdmap, grids, tcell, src, src0, nn, queue, wgtab, prm);
 }
 
 }  // namespace cd
