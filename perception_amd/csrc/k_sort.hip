@@ -39,6 +39,17 @@ __device__ __forceinline__ uint32_t voxel_key(uint32_t a, const KeyPack& kp, con
     return (uint32_t)(i0 + i1 * g.d0 + i2 * g.d01);
 }
 
+#ifdef CD_SORTDBG
+__device__ unsigned long long g_sort_dbg[8];
+extern "C" int cd_debug_sort(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sort_dbg), sizeof(g_sort_dbg)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sort_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define SORT_PHASE(k) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_sort_dbg[k], t_ - t0_); t0_ = t_; } }
+#else
+#define SORT_PHASE(k)
+#endif
 constexpr int SORT_MAX_PASSES = 4;
 constexpr int GHIST_TILES = 4;   // sort tiles per workgroup of the histogram kernel (fewer global flushes)
 
@@ -99,36 +110,50 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     const int n = fs[f].n_c;
     if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
+#ifdef CD_SORTDBG
+    unsigned long long t0_ = wall_clock64();
+    if (threadIdx.x == 0) atomicAdd(&g_sort_dbg[7], 1ull);
+#endif
     for (int q = threadIdx.x; q < SORT_WAVES * RADIX; q += SORT_BLOCK) (&s_wh[0][0])[q] = 0;
     __syncthreads();
     const int base = tile * SORT_TILE + w * WAVE_SPAN + lane;
     const uint64_t lt = lanemask_lt();
     const KeyGrid g = key_grid(fs[f]);
-    uint32_t key[ITEMS], rank[ITEMS];
+    uint32_t key[ITEMS], rank[ITEMS], val[ITEMS];
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {   // all loads of the tile go out together (the values are only needed for the staging)
+        const int e = base + j * WAVE;
+        key[j] = e < n ? kin[fbase + e] : 0xffffffffu;
+        val[j] = e < n ? (vin ? vin[fbase + e] : (uint32_t)e) : 0u;
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         const bool valid = e < n;
-        key[j] = valid ? kin[fbase + e] : 0xffffffffu;
         if (kp.enabled && valid) key[j] = voxel_key(key[j], kp, g);
         const uint32_t d = (key[j] >> shift) & (RADIX - 1);
-        uint64_t peers = __ballot(valid);
+        // match-any over the 8 digit bits: lanes that differ from this one in some bit are collected in two 32-bit halves
+        // (per bit: sign-extended bit, one compare for the ballot, xor + or per half - written out this way because the
+        // 64-bit select form "peers &= bit ? m : ~m" compiled to twice the vector instructions, and this loop is what the
+        // scatter's ranking costs)
+        uint32_t dl = 0u, dh = 0u;
 #pragma unroll
         for (int b = 0; b < RADIX_BITS; ++b) {
-            const bool bit = (d >> b) & 1u;
-            const uint64_t m = __ballot(bit);
-            peers &= bit ? m : ~m;
+            const int y = (int)(d << (31 - b)) >> 31;          // all ones where this lane's bit b is set
+            const uint64_t m = __ballot(y < 0);
+            dl |= (uint32_t)m ^ (uint32_t)y;
+            dh |= (uint32_t)(m >> 32) ^ (uint32_t)y;
         }
-        const int leader = valid ? (__ffsll((long long)peers) - 1) : lane;
+        const uint64_t peers = ~(((uint64_t)dh << 32) | dl) & __ballot(valid);   // same digit, and a real element
+        // every lane reads its bin's running count, then the LAST lane of each group of equal digits adds the group's size
+        // (the LDS executes a wave's operations in order: all reads see the count before any of this row's updates)
         uint32_t bin_base = 0;
-        if (valid && lane == leader) {
-            bin_base = s_wh[w][d];
-            s_wh[w][d] = (unsigned short)(bin_base + (uint32_t)__popcll(peers));
-        }
-        bin_base = __shfl(bin_base, leader, 64);
+        if (valid) bin_base = s_wh[w][d];
+        if (valid && (peers >> lane) == 1ull) s_wh[w][d] = (unsigned short)(bin_base + (uint32_t)__popcll(peers));
         rank[j] = bin_base + (uint32_t)__popcll(peers & lt);
     }
     __syncthreads();
+    SORT_PHASE(0)
     if (threadIdx.x < RADIX) {   // per-digit exclusive prefix over the waves, then over the digits
         const int d = threadIdx.x;
         uint32_t run = 0;
@@ -160,6 +185,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
         s_goff[threadIdx.x] += gadd;
     }
     __syncthreads();
+    SORT_PHASE(1)
     // the tile in bin order, staged in LDS: the global stores below are then contiguous runs (one run per bin) instead of
     // 64 scattered 4-byte stores per instruction
 #pragma unroll
@@ -169,10 +195,11 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
             const uint32_t d = (key[j] >> shift) & (RADIX - 1);
             const uint32_t lp = s_bstart[d] + s_wh[w][d] + rank[j];
             s_k[lp] = key[j];
-            s_v[lp] = vin ? vin[fbase + e] : (uint32_t)e;
+            s_v[lp] = val[j];
         }
     }
     __syncthreads();
+    SORT_PHASE(2)
     const int cnt = min(SORT_TILE, n - tile * SORT_TILE);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
@@ -185,6 +212,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
             vout[fbase + dst] = s_v[lp];
         }
     }
+    SORT_PHASE(3)
 }
 
 // All passes of one sort.  Tact = sort tiles that hold data (max over the frames).  ghist [F][SORT_MAX_PASSES][RADIX] and
