@@ -369,9 +369,12 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
         int cnt = 0;
         for (int e = e0;; e += 4) {
             const int me = e + ql;
-            const bool mine = me < n && k[me] == key;     // members of a run are contiguous in sorted order
+            // key and index of the candidate member are fetched together (one round trip before the gather, not two)
+            uint32_t kk = ~key, vv = 0;
+            if (me < n) { kk = k[me]; vv = v[me]; }
+            const bool mine = kk == key;                  // members of a run are contiguous in sorted order
             float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (mine) p = cpt[fbase + v[me]];
+            if (mine) p = cpt[fbase + vv];
             const int m0 = quad_bcast_i<0>(mine), m1 = quad_bcast_i<1>(mine), m2 = quad_bcast_i<2>(mine), m3 = quad_bcast_i<3>(mine);
 #define CD_ACC(I, M)                                                                                   \
             if (M) {                                                                                   \
