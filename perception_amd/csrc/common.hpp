@@ -137,6 +137,9 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o) {
     return f;
 #endif
 }
+// wave ballot of a BOOL: HIP's __ballot(int) first turns a lane mask that is already in SGPRs (e.g. a && of two compares)
+// into a 0/1 vector and compares it again - two vector instructions per loop condition in the ICP search loops
+__device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint64_t lanemask_lt() {
     const uint32_t lane = threadIdx.x & 63;
     return (lane == 0) ? 0ull : (~0ull >> (64 - lane));

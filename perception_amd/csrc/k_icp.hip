@@ -337,7 +337,6 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
     // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
     // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it)
     unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
-    int lbi = q.pbi;
     const float slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
     const float sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
     const float slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
@@ -347,19 +346,21 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
     int ry = y0, rz = grid_coord(__fsub_rn(q.pz, rzz), g.oz, g.inv, g.nz);
     const float rr2 = __fmul_rn(__fmul_rn(rr, rr), 1.0f + 1.0e-6f);
     const float huge = 3.0e38f;
-    int i = 0, b = 0;
+    // a lane whose walk is over (or that takes no part) has b = INT_MIN: "i < b" alone then says "has a point to test"
+    int i = 0, b = act ? 0 : (-0x7fffffff - 1);
     bool more = act;
     for (;;) {
         // A: every lane that has used up its range advances to its next row with a non-empty range
         bool need = more && i >= b;
-        while (__ballot(need)) {
+        while (ballot64(need)) {
 #ifdef CD_STATS
-            { const unsigned long long nb_ = __ballot(need); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
+            { const unsigned long long nb_ = ballot64(need); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
 #endif
             if (need) {
                 if (rz > z1) {
                     more = false;
                     need = false;
+                    b = -0x7fffffff - 1;
                 } else {
                     // slab of row (ry, rz); the outermost cells are open-ended (they also hold whatever rounding put past the box)
                     const float ylo = ry == 0 ? -huge : __fadd_rn(g.oy, __fmul_rn((float)ry, g.cell));
@@ -381,30 +382,29 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
                 }
             }
         }
-        if (!__ballot(more)) break;
-        // B: test the points of the current ranges, two per trip
-        while (__ballot(more && i < b)) {
+        if (!ballot64(more)) break;
+        // B: test the points of the current ranges, two per trip.  No lane is switched off: a lane whose range is used up (or
+        // whose walk is over) simply tests the points that follow it - real template points, which can never displace the true
+        // neighbour - clamped to the +inf pad point.  The low word of the key is (original index << 13 | stored position), so
+        // the winner's position needs no select of its own.
+        while (ballot64(i < b)) {
 #ifdef CD_STATS
-            { const unsigned long long pb_ = __ballot(more && i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
+            { const unsigned long long pb_ = ballot64(i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
 #endif
-            const bool on = more && i < b;
-            const int i0 = on ? i : pad;
-            const int i1 = (on && i + 1 < b) ? i + 1 : pad;
+            const int i0 = min(i, pad), i1 = min(i + 1, pad);
             const float4 t = s_tpl[i0];
             const float4 u = s_tpl[i1];
             const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
             const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
-            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(t.w);
-            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (unsigned)__float_as_int(u.w);
-            const bool up = kd_ < lkey;
-            lkey = up ? kd_ : lkey; lbi = up ? i0 : lbi;
-            const bool up1 = ke_ < lkey;
-            lkey = up1 ? ke_ : lkey; lbi = up1 ? i1 : lbi;
-            i = on ? i + 2 : i;
+            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << 13) | (unsigned)i0);
+            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << 13) | (unsigned)i1);
+            lkey = kd_ < lkey ? kd_ : lkey;
+            lkey = ke_ < lkey ? ke_ : lkey;
+            i += 2;
         }
     }
-    const int loi = (int)(unsigned)(lkey & 0xffffffffull);
-    if (act && loi != 0x7fffffff) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = lbi; q.poi = loi; }
+    const unsigned lo = (unsigned)(lkey & 0xffffffffull);
+    if (act && lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
 }
 
 // Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
@@ -426,8 +426,8 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
         // carried over from a lower chunk (c0 > 0) must ties against the carried neighbour be decided,
         // so only then is its original index needed.
         const int boi = c0 > 0 ? __builtin_amdgcn_readlane(q.poi, k) : 0x7fffffff;
-        unsigned long long m0 = __ballot(box_lb(bx.L0, bx.H0, x, y, z) <= best);
-        unsigned long long m1 = __ballot(box_lb(bx.L1, bx.H1, x, y, z) <= best);
+        unsigned long long m0 = ballot64(box_lb(bx.L0, bx.H0, x, y, z) <= best);
+        unsigned long long m1 = ballot64(box_lb(bx.L1, bx.H1, x, y, z) <= best);
 #ifdef CD_STATS
         if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(m0) + __popcll(m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
@@ -457,7 +457,7 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
         // bound can hold it; when exactly one did (the usual case once seeds are tight) it IS the answer
         // and three v_readlane replace the reduction.  Otherwise: min distance by DPP, then the lowest
         // original index among the lanes that hold it.
-        const unsigned long long imp = __ballot(lbest < best || (lbest == best && loi < boi));
+        const unsigned long long imp = ballot64(lbest < best || (lbest == best && loi < boi));
         if (imp == 0) continue;   // nothing in this chunk beats the carried neighbour (multi-chunk templates only)
         float dmin;
         int rbi, roi;
@@ -468,7 +468,7 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
             roi = __builtin_amdgcn_readlane(loi, l);
         } else {
             dmin = wave_min_f32_nonneg(lbest);
-            unsigned long long eq = __ballot(lbest == dmin);
+            unsigned long long eq = ballot64(lbest == dmin);
             rbi = 0; roi = 0x7fffffff;
             while (eq) {
                 const int l = __ffsll((long long)eq) - 1;
@@ -501,8 +501,8 @@ __device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const Que
     f.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
     const int nd = __builtin_amdgcn_readlane(need, k);
     f.m0 = 0ull; f.m1 = 0ull;
-    if (nd & 1) f.m0 = __ballot(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
-    if (nd & 2) f.m1 = __ballot(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
+    if (nd & 1) f.m0 = ballot64(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
+    if (nd & 2) f.m1 = ballot64(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
     // lanes start from (bound, no index): a lane can only be selected if it beat the bound, and the seed point itself does
     f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
 }
@@ -532,7 +532,7 @@ __device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsi
     // lanes whose key beats the bound.  None: the query keeps its seed.  Exactly one (the usual case once the seeds are
     // tight: the seed point itself, in the one patch that holds it): that key IS the minimum, fetched with two readlanes.
     // Several: LDS 64-bit min over them.
-    const unsigned long long imp = __ballot(f.lkey < bound);
+    const unsigned long long imp = ballot64(f.lkey < bound);
     if (imp == 0ull) return;
     unsigned long long res;
     if ((imp & (imp - 1ull)) == 0ull) {
@@ -852,12 +852,12 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
                     CD_PHASE(1)
 #ifdef CD_STATS
-                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+                    { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
-                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, __ballot(lane < nk && !near));
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, ballot64(lane < nk && !near));
                     CD_PHASE(2)
                 } else {
                     for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
@@ -947,11 +947,11 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk && grid_ok) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
-                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+                    { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
-                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, __ballot(lane < nk && !near));
+                    search_chunk(s_tpl, bx, 0, c.tpl_m, q, ballot64(lane < nk && !near));
                 } else {
                     for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
                         const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
@@ -1186,9 +1186,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (__ballot(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
-                    { const unsigned long long nb_ = __ballot(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+                    { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
                     // which halves of the template can hold a point within this lane's bound (all lanes at once)
                     const float4 hl0 = make_float4(g.half_lo[0][0], g.half_lo[0][1], g.half_lo[0][2], 0.f), hh0 = make_float4(g.half_hi[0][0], g.half_hi[0][1], g.half_hi[0][2], 0.f);
@@ -1196,13 +1196,13 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, __ballot(lane < nk && !near), psplit, need, &s_far[wave]);
+                    search_patches(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave]);
 #endif
                     // The pass's 16 moment terms go into the slot's accumulators right away: no sum is carried in registers
                     // across the searches (32 VGPRs that the search loops would otherwise spill around).
