@@ -372,7 +372,8 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
                     const float e2 = __fmul_rn(__fadd_rn(__fmul_rn(ey, ey), __fmul_rn(ez, ez)), 1.0f - 1.0e-6f);
                     const float rem = __fsub_rn(rr2, e2);
                     if (rem >= 0.f) {
-                        const float rx = __fadd_rn(__fmul_rn(__fsqrt_rn(rem), 1.0f + 1.0e-6f), slx);
+                        // (a bound, not a result: the hardware square root is within 1 ulp, far inside the 1e-6 margin)
+                        const float rx = __fadd_rn(__fmul_rn(__builtin_amdgcn_sqrtf(rem), 1.0f + 1.0e-6f), slx);
                         const int row = (rz * g.ny + ry) * g.nx;
                         i = s_cs[row + grid_coord(__fsub_rn(q.px, rx), g.ox, g.inv, g.nx)];
                         b = s_cs[row + grid_coord(__fadd_rn(q.px, rx), g.ox, g.inv, g.nx) + 1];
