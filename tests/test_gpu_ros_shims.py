@@ -52,3 +52,79 @@ def test_gps_node_publishes_the_input_layout(O, tmp_path):
     assert np.array_equal(rec[:, 16:20].copy().view(np.uint32).ravel(), rgb[keep])
     assert not rec[:, 12:16].any() and not rec[:, 20:32].any()          # padding is zero, not the input's junk
     assert np.array_equal(coeff.view(np.uint32), c1.view(np.uint32))
+
+
+def test_gps_and_icp_nodes_chained(O, template, tmp_path):
+    """iterative_closest_point.launch: gps publishes, icp subscribes.  Both node shims (separate objects, linked against the
+    roscpp stand-ins) run back to back on one frame: /icp/pose, /icp/bbox_points and the TF must be what the oracle gives
+    for the reference's chain (icp.cpp:150-182 on the whole extracted cloud, publish_pose / publish_bounding_box
+    icp.cpp:55-128), the aligned cloud and the template are published once, and the second frame only republishes the
+    latched result (icp.cpp:139-147)."""
+    from perception_amd import templates
+    subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
+    frame = synth.frame(0)
+    fin, tpath = str(tmp_path / "frame.bin"), str(tmp_path / "template.pcd")
+    frame.astype(np.float32).tofile(fin)
+    open(tpath, "wb").write(templates.template_pcd_bytes(**templates.DEFAULT_TEMPLATE))
+    out = subprocess.run([os.path.join(CPP, "chain_shim_driver"), fin, tpath, "0.0004"], check=True, capture_output=True, text=True,
+                         timeout=120).stdout
+    d = {ln.split()[0]: ln.split()[1:] for ln in out.strip().splitlines()}
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    st, vox, rgb, _, _ = O.crop_voxel(frame, prm, want_rgb=True)
+    s1, c1, inl, _ = O.segment_plane(vox, prm)
+    keep = np.ones(len(vox), bool)
+    keep[inl] = False
+    src = vox[keep]
+    s2, r, _ = O.icp(template, src, prm, nn_mode=1)
+    assert st == 0 and s1 == 0 and s2 == 0 and r.accepted == 1
+    assert d["gps_points"] == [str(len(src)), "point_step", "32"]
+    assert d["published"] == ["pose", "1", "bbox", "1", "aligned", "1", "template", "1", "tf", "1"]
+    pose = np.array(r.pose).reshape(4, 4)
+    pos, q = O.pose_to_position_quaternion(pose)
+    got = [float.fromhex(t) for t in d["pose"] if t != "quat"]
+    assert got == list(pos) + list(q)
+    box = O.bbox_corners(pose, 0.2, 0.1, 0.03)
+    assert [float.fromhex(t) for t in d["bbox"]] == [float(v) for v in box.ravel()]
+    assert d["aligned_points"] == [str(len(src))] and d["template_points"] == [str(len(template))]
+    assert d["tf"] == ["camera_depth_optical_frame", "->", "icp_cuboid_frame"]
+    assert d["republished"] == ["1", "aligned_again", "1"]
+
+
+def test_opd_node_service_and_cached_pose(O, tmp_path):
+    """object_pose_detection: a frame arrives, `detect_objects` is called for the screwdriver (id 1: template of 1370 points,
+    the closest cluster differs by 42 < 250: success, opd.cpp:416-429) and for the eraser (id 2: 2979 points, every cluster is
+    more than 1000 points away: the pick finds nothing, failure); after the success every new frame republishes the cached
+    pose (opd.cpp:257-267).  Chosen cluster, its transformation and the published pose against the oracle."""
+    from conftest import GOLDEN
+    from perception_amd import pcd
+    subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
+    frame = synth.frame(1)
+    fin = str(tmp_path / "frame.bin")
+    frame.astype(np.float32).tofile(fin)
+    out = subprocess.run([os.path.join(CPP, "opd_shim_driver"), fin, GOLDEN + os.sep, "0.005", "0.01", "1", "2"], check=True,
+                         capture_output=True, text=True, timeout=120).stdout
+    lines = [ln.split() for ln in out.strip().splitlines()]
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    prm.leaf_size = 0.005
+    prm.plane_distance_threshold = 0.01
+    prm.crop2_enable = 1
+    prm.cluster_enable = 1
+    tpl = pcd.read_xyz(os.path.join(GOLDEN, "screwdriver_ascii_tf.pcd")).astype(np.float32)
+    ro = O.process_frame(frame, prm, tpl)["result"]
+    sizes = [ro.clusters[k].size for k in range(ro.n_clusters)]
+    diffs = [abs(s - len(tpl)) for s in sizes]
+    k = int(np.argmin(diffs))
+    assert diffs[k] < 250
+    c = ro.clusters[k]
+    assert lines[0] == ["service", "id", "1", "returned", "1", "success", "1"]
+    assert lines[1][:7] == ["chosen", "size", str(c.size), "iterations", str(c.iterations), "accepted", str(c.accepted)]
+    assert float.fromhex(lines[1][8]) == c.fitness
+    assert [float.fromhex(t) for t in lines[2][1:]] == [float(v) for v in c.T]
+    assert lines[3] == ["poses_published", "1"]
+    pos, q = O.pose_to_position_quaternion(np.array(c.pose).reshape(4, 4))
+    assert [float.fromhex(t) for t in lines[4] if t not in ("pose", "quat")] == list(pos) + list(q)
+    # eraser: no cluster within 1000 points of the template's size -> failure; the earlier success is gone (ICP_SUCCESS false)
+    assert lines[5] == ["service", "id", "2", "returned", "0", "success", "0"]
+    assert lines[6] == ["poses_published", "0"]
