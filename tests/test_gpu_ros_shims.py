@@ -128,3 +128,52 @@ def test_opd_node_service_and_cached_pose(O, tmp_path):
     # eraser: no cluster within 1000 points of the template's size -> failure; the earlier success is gone (ICP_SUCCESS false)
     assert lines[5] == ["service", "id", "2", "returned", "0", "success", "0"]
     assert lines[6] == ["poses_published", "0"]
+
+
+def test_bbox_filter_and_surface_normal_nodes(O, tmp_path):
+    """bbox_filter: everything is rejected until a CameraInfo has arrived (bbox_filter.cpp:33-34), then the kept records
+    are the input's own records (all fields) of the points whose projection falls strictly inside the rectangle (:30-51,
+    :96-101).  surface_normal_estimation: silent until the table plane's coefficients have arrived (sne.cpp:170), then pose, TF
+    and the three plane coefficient messages (:231-233) - all against the oracle."""
+    from conftest import rot_xyz
+    from test_oracle_kat import _corner_cloud
+    subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
+    drv = os.path.join(CPP, "bbox_sne_shim_driver")
+    # --- bbox_filter
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    st, vox, rgb, _, _ = O.crop_voxel(synth.frame(3), prm, want_rgb=True)
+    cloud = np.zeros((len(vox), 4), np.float32)
+    cloud[:, :3] = vox
+    cloud[:, 3] = rgb.view(np.float32)
+    fin, fout = str(tmp_path / "cloud.bin"), str(tmp_path / "out.bin")
+    cloud.tofile(fin)
+    P = [615.0, 0.0, 320.0, 0.0, 0.0, 615.0, 240.0, 0.0, 0.0, 0.0, 1.0, 0.0]
+    rect = [250, 180, 420, 330]
+    out = subprocess.run([drv, "bbox", fin, fout] + [repr(v) for v in P] + [str(v) for v in rect], check=True, capture_output=True,
+                         text=True, timeout=120).stdout.strip().splitlines()
+    idx = O.bbox_filter(vox, P, rect)
+    assert 0 < len(idx) < len(vox)
+    assert out[0].split() == ["before_camera_info", "width", "0"]
+    assert out[1].split() == ["after", "width", str(len(idx)), "point_step", "16", "fields", "4", "publications", "2"]
+    assert open(fout, "rb").read() == cloud[idx].tobytes()
+    # --- surface_normal_estimation
+    rng = np.random.default_rng(21)
+    R = rot_xyz(0.35, -0.2, 0.6)
+    pts = _corner_cloud(R, np.array([0.02, -0.03, 0.55]), rng).astype(np.float32)
+    ax = R[:, 2].astype(np.float32)
+    fin2 = str(tmp_path / "corner.bin")
+    np.ascontiguousarray(pts[:, :3], np.float32).tofile(fin2)
+    out = subprocess.run([drv, "sne", fin2, repr(float(ax[0])), repr(float(ax[1])), repr(float(ax[2])), "0.002"], check=True,
+                         capture_output=True, text=True, timeout=120).stdout.strip().splitlines()
+    prm = capi.default_params()
+    prm.plane_distance_threshold = 0.002
+    so, ro = O.surface_frame(np.ascontiguousarray(pts[:, :3], np.float32), ax, prm)
+    assert so == 0
+    assert out[0].split() == ["before_coefficients", "poses", "0"]
+    assert out[1].split() == ["after", "poses", "1", "tf", "1"]
+    pos, q = O.pose_to_position_quaternion(np.array(ro.Rt, np.float64).reshape(4, 4))
+    assert [float.fromhex(t) for t in out[2].split() if t not in ("pose", "quat")] == list(pos) + list(q)
+    for line, k in zip(out[3:6], (2, 1, 0)):                          # normal_x <- coeff[2], normal_y <- coeff[1], normal_z <- coeff[0]
+        assert [float.fromhex(t) for t in line.split()[1:]] == [float(v) for v in ro.coeff[k]]
+    assert out[6].split() == ["tf", "camera_depth_optical_frame", "->", "estimated_cuboid_frame"]
