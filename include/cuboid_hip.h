@@ -182,6 +182,13 @@ int cd_segment_plane(cd_context* ctx, const void* xyz, size_t stride_bytes, int 
 int cd_surface_frame(cd_context* ctx, const void* xyz, size_t stride_bytes, int n, const float table_normal[3],
                      int invert, const cd_params* prm, cd_surface_frame_result* out);
 
+/* S3 as a call of its own: pcl::ExtractIndices<PCLPointCloud2> (gps.cpp:96-101, opd.cpp:320-326; the fused calls extract
+ * internally).  negative == 0: the records at `indices`, in the order of the list; negative != 0: the records whose index
+ * is NOT in the list, in their original order (what both launch files use: setNegative(invert = true)).  Records are copied
+ * whole - every field of the PointCloud2 blob - `stride_bytes` (a multiple of 4) each.  out_points holds `capacity` records. */
+int cd_extract(cd_context* ctx, const void* points, size_t stride_bytes, int n, const int32_t* indices, int n_indices,
+               int negative, void* out_points, int capacity, int* out_n);
+
 /* bbox_filter: indices (ascending) of the points whose projection lies strictly inside the image
  * rectangle - cuboid_detection/src/bbox_filter.cpp:30-51 (within_bbox) and :84-103 (pcl_cb builds the
  * inlier list that its ExtractIndices keeps).  P = CameraInfo.P, row-major 3x4; rect = x1,y1,x2,y2.

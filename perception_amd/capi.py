@@ -28,7 +28,7 @@ LIB_PATH = os.environ.get("CUBOID_HIP_LIB") or os.path.join(os.path.dirname(os.p
 # every symbol include/cuboid_hip.h declares (checked by tests/test_abi.py)
 EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
-    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
+    "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_extract", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_frame", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing",
 ]
@@ -155,6 +155,7 @@ def load_library(path=None):
                                      C.c_int, ip, ip]
     lib.cd_surface_frame.argtypes = [vp, vp, C.c_size_t, C.c_int, f32p, C.c_int, C.POINTER(CdParams), C.POINTER(CdSurfaceFrameResult)]
     lib.cd_bbox_filter.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, vp, vp, C.c_int, ip]
+    lib.cd_extract.argtypes = [vp, vp, C.c_size_t, C.c_int, vp, C.c_int, C.c_int, vp, C.c_int, ip]
     lib.cd_cluster.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), vp, vp, C.c_int, ip]
     lib.cd_icp.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(CdParams),
                            C.POINTER(CdClusterResult), vp]
@@ -284,6 +285,17 @@ class Context:
         self._check(self.lib.cd_process_batch(self.h, _ptr(f), Cc * 4, N, F, C.byref(prm),
                                               C.cast(res, C.c_void_p), _ptr(pi), _ptr(lb)))
         return res, pi, lb
+
+    def extract(self, records, indices, negative=True):
+        """pcl::ExtractIndices on whole records: `records` is an (n, k) array of 4-byte items (all fields of a point)."""
+        r = np.ascontiguousarray(records)
+        assert r.ndim == 2 and r.dtype.itemsize == 4
+        idx = np.ascontiguousarray(indices, dtype=np.int32)
+        n, stride = r.shape[0], r.shape[1] * 4
+        out = np.empty((n if negative else len(idx), r.shape[1]), r.dtype)
+        cnt = C.c_int()
+        self._check(self.lib.cd_extract(self.h, _ptr(r), stride, n, _ptr(idx), len(idx), 1 if negative else 0, _ptr(out), len(out), C.byref(cnt)))
+        return out[:cnt.value].copy()
 
     def process_frame(self, points, prm, want_indices=False):
         """One frame (N, C>=3) float32: the reference's callback body as one call.  Returns (result, plane_inliers, labels)."""

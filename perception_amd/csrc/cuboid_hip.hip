@@ -1444,6 +1444,56 @@ int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const d
     return CD_OK;
 }
 
+int cd_extract(cd_context* c, const void* points, size_t stride, int n, const int32_t* indices, int n_indices, int negative,
+               void* out_points, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if ((!points && n > 0) || (!indices && n_indices > 0) || !out_n || n < 0 || n_indices < 0 || capacity < 0 || stride < 4 || (stride & 3) ||
+        (!out_points && capacity > 0))
+        return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (n > c->N || (!negative && n_indices > c->N)) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    if (n == 0) return CD_OK;
+    const int words = (int)(stride / 4);
+    // staging buffer: the input records, then room for the records that are kept
+    const size_t in_bytes = ((size_t)n * stride + 255) & ~(size_t)255;
+    int st = ensure_input(c, in_bytes + (size_t)(negative ? n : n_indices) * stride);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, points, (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
+    // index list -> d_label (upload), kept indices -> d_plane_idx
+    const int mi = std::min(n_indices, c->N);
+    if (mi > 0) HIPCHK(c, hipMemcpyAsync(c->d_label, indices, sizeof(int) * (size_t)mi, hipMemcpyHostToDevice, c->stream));
+    int kept = 0;
+    const int* d_keep = c->d_label;
+    if (negative) {
+        if (n_indices > c->N) return fail(c, CD_ERR_CAPACITY, "index list longer than the context capacity");
+        std::memset(&c->h_fs[0], 0, sizeof(FrameState));
+        HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_rank, 0, sizeof(int) * (size_t)n, c->stream));            // marks
+        HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)c->T, c->stream));          // chained-scan state
+        LAUNCH(c, launch_mark_indices(c->stream, c->d_label, mi, n, c->d_rank));
+        LAUNCH(c, launch_select_unmarked(c->stream, c->d_rank, n, c->d_tileA, c->d_fs, c->d_plane_idx));
+        st = sync_fs(c, 1);
+        if (st) return st;
+        kept = c->h_fs[0].n_plane;
+        d_keep = c->d_plane_idx;
+    } else {
+        for (int i = 0; i < n_indices; ++i)
+            if (indices[i] < 0 || indices[i] >= n) return fail(c, CD_ERR_INVALID_ARG, "index out of range");
+        kept = n_indices;
+    }
+    if (kept > capacity) return fail(c, CD_ERR_CAPACITY, "output capacity too small");
+    if (kept > 0) {
+        char* d_out = (char*)c->d_in + in_bytes;
+        LAUNCH(c, launch_gather_records(c->stream, c->d_in, words, d_keep, kept, d_out));
+        HIPCHK(c, copy_sync(c, out_points, d_out, (size_t)kept * stride, hipMemcpyDeviceToHost));
+    } else {
+        HIPCHK(c, hipStreamSynchronize(c->stream));   // the uploads read caller memory
+    }
+    *out_n = kept;
+    return CD_OK;
+}
+
 int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels,
                int32_t* sizes, int sizes_capacity, int* out_k) {
     if (!c) return CD_ERR_INVALID_ARG;

@@ -292,4 +292,62 @@ void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int 
                        crop2, z2lo, z2hi, gate, off_plane, off_obj, plane_idx, obj);
 }
 
+// ---- S3 as a call of its own: pcl::ExtractIndices<PCLPointCloud2> on whole records --------------------------------------
+// (the fused path extracts inside k_extract_scatter; these serve cd_extract.)  Records are `words` 4-byte words.
+__global__ void __launch_bounds__(BLOCK) k_mark_indices(const int* __restrict__ idx, int m, int n, int* __restrict__ flag) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < m) { const int k = idx[i]; if (k >= 0 && k < n) flag[k] = 1; }
+}
+// positions i with flag[i] == 0, ascending (ordered compaction: ballots + chained scan over the tiles)
+__global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict__ flag, int n, int* __restrict__ state,
+                                                           FrameState* __restrict__ fs, int* __restrict__ out) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ int s_excl;
+    const int tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int base = tile * TILE + w * WAVE_SPAN;
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE + lane;
+        bal[j] = ballot64(e < n && flag[e] == 0);
+        wtot += __popcll(bal[j]);
+    }
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) tot += s_cnt[k];
+        const int excl = chained_scan(state, 1, tile, tot, &fs[0].scan_stalled);
+        s_excl = excl;
+        if ((tile + 1) * TILE >= n) fs[0].n_plane = excl + tot;
+    }
+    __syncthreads();
+    int pos = s_excl;
+    for (int k = 0; k < w; ++k) pos += s_cnt[k];
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) out[pos + __popcll(bal[j] & lt)] = base + j * WAVE + lane;
+        pos += __popcll(bal[j]);
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_gather_records(const uint32_t* __restrict__ in, int words, const int* __restrict__ idx,
+                                                          int m, uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)m * words) return;
+    const int r = (int)(t / words), wd = (int)(t % words);
+    out[t] = in[(size_t)idx[r] * words + wd];
+}
+void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag) {
+    if (m > 0) hipLaunchKernelGGL(k_mark_indices, dim3((m + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, idx, m, n, flag);
+}
+void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out) {
+    hipLaunchKernelGGL(k_select_unmarked, dim3((n + TILE - 1) / TILE), dim3(BLOCK), 0, s, flag, n, state, fs, out);
+}
+void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out) {
+    const size_t tot = (size_t)m * words;
+    if (tot > 0) hipLaunchKernelGGL(k_gather_records, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, (const uint32_t*)in, words, idx, m, (uint32_t*)out);
+}
+
 }  // namespace cd

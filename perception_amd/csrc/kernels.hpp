@@ -16,6 +16,10 @@ void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, in
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
 
+void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
+void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out);
+void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out);
+
 // k_sort.hip : segmented (per frame) stable LSD radix sort of (key, value) pairs, all passes
 constexpr int SORT_MAX_PASSES_HOST = 4;
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,

@@ -266,6 +266,32 @@ def test_icp_large_template_and_real_cluster(ctx, O):
     _same_cluster(res, r0)
 
 
+def test_extract_indices_keeps_whole_records(ctx, O, frames4):
+    """cd_extract = pcl::ExtractIndices<PCLPointCloud2> (gps.cpp:96-101): negative keeps the records NOT listed, in order;
+    positive the listed ones in list order; 16-, 20- and 32-byte records come back field for field."""
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    st, vox, rgb, _, _ = O.crop_voxel(frames4[0], prm, want_rgb=True)
+    s1, c1, inl, _ = O.segment_plane(vox, prm)
+    rng = np.random.RandomState(3)
+    for words in (4, 5, 8):
+        rec = rng.randint(0, 2 ** 31, (len(vox), words)).astype(np.uint32)
+        rec[:, :3] = vox.view(np.uint32)
+        got = ctx.extract(rec, inl, negative=True)
+        keep = np.ones(len(vox), bool)
+        keep[inl] = False
+        assert np.array_equal(got, rec[keep])
+        pick = rng.permutation(len(vox))[:777].astype(np.int32)
+        assert np.array_equal(ctx.extract(rec, pick, negative=False), rec[pick])
+    # edges: empty list, everything listed, duplicates and out-of-range entries in a negative list, ragged tile ends
+    rec = np.arange(2049 * 4, dtype=np.uint32).reshape(2049, 4)
+    assert np.array_equal(ctx.extract(rec, np.zeros(0, np.int32)), rec)
+    assert len(ctx.extract(rec, np.arange(2049, dtype=np.int32))) == 0
+    assert np.array_equal(ctx.extract(rec, np.array([5, 5, 2048, -3, 99999], np.int32)), np.delete(rec, [5, 2048], 0))
+    with pytest.raises(capi.CuboidError):
+        ctx.extract(rec, np.array([2049], np.int32), negative=False)
+
+
 def test_process_frame_is_a_batch_of_one(ctx, frames4):
     prm = capi.default_params()
     prm.rgb_offset = 12
