@@ -29,6 +29,7 @@ constexpr int ICP_SUB = 64;                // template run length that carries o
 constexpr int ICP_TPL_LDS = 7616;          // template points resident in LDS (119 runs, 119 KiB)
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
+constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS
 constexpr int ICP_QSLICE = 512;            // max ICP source points (queries) per work item / workgroup
 
 // Per-frame scalars that live on the device and are mirrored to pinned host memory.
@@ -97,6 +98,12 @@ struct IcpGrid {
     int32_t kd_split;
     int32_t pad;
     float half_lo[2][4], half_hi[2][4];
+    // templates that do not fit LDS are searched chunk by chunk: the chunks are whole k-d subtrees of at most ICP_TPL_LDS
+    // points (compact regions), with their boxes, so that a workgroup only stages the chunks its queries can reach
+    int32_t nchunk;        // 0: fixed chunks of ICP_TPL_LDS points (more than ICP_MAX_CHUNKS subtrees)
+    int32_t chunk_start[ICP_MAX_CHUNKS], chunk_n[ICP_MAX_CHUNKS];
+    int32_t pad2[3];
+    float chunk_lo[ICP_MAX_CHUNKS][4], chunk_hi[ICP_MAX_CHUNKS][4];
 };
 
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity

@@ -558,7 +558,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int group = 8;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
-        for (int q = 0; q < g; ++q) LAUNCH(c, launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tplk, c->d_tlok, c->d_thik, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip));
+        for (int q = 0; q < g; ++q) LAUNCH(c, launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip));
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
@@ -577,7 +577,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
-    LAUNCH(c, launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_src0, c->d_nn, c->d_d2, qslice));
+    LAUNCH(c, launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_src0, c->d_nn, c->d_d2, qslice));
     HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1142,6 +1142,7 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
     layout(P->cell_pts, P->cell_lo, P->cell_hi);                      // layout 1: cell-sorted (whole-cluster kernels)
     std::vector<int> pos_cell((size_t)m);                             // original index -> position in layout 1
     for (int i = 0; i < m; ++i) pos_cell[(size_t)tp[(size_t)i].oi] = i;
+    std::vector<std::pair<int, int>> chunks;  // k-d subtrees of <= ICP_TPL_LDS points whose parent is larger (templates that do not fit LDS)
     {
         // Layout 2, for the wave-per-query search: compact patches of 64 points from k-d median splits whose left part is
         // a multiple of 64, so that consecutive runs of 64 stored points have the smallest boxes the run-box pruning can get.
@@ -1151,6 +1152,11 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
             const auto [lo, hi] = stack.back();
             stack.pop_back();
             const int n = hi - lo;
+            if (m > ICP_TPL_LDS && n <= ICP_TPL_LDS) {
+                bool inside = false;   // already inside a recorded chunk?
+                for (const auto& ch : chunks) inside = inside || (lo >= ch.first && hi <= ch.second);
+                if (!inside) chunks.push_back({lo, hi});
+            }
             if (n <= ICP_SUB) {
                 std::sort(tp.begin() + lo, tp.begin() + hi, [](const TP& a, const TP& bb) { return a.oi < bb.oi; });
                 continue;
@@ -1173,6 +1179,23 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
         }
     }
     layout(P->kd_pts, P->kd_lo, P->kd_hi);
+    if (m > ICP_TPL_LDS && (int)chunks.size() <= ICP_MAX_CHUNKS) {   // chunk table of a template that does not fit LDS
+        std::sort(chunks.begin(), chunks.end());
+        grid.nchunk = (int)chunks.size();
+        for (int ci = 0; ci < grid.nchunk; ++ci) {
+            const int lo = chunks[(size_t)ci].first, hi = chunks[(size_t)ci].second;
+            grid.chunk_start[ci] = lo;
+            grid.chunk_n[ci] = hi - lo;
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int r = lo / ICP_SUB; r < (hi + ICP_SUB - 1) / ICP_SUB; ++r) {
+                const float lo3[3] = {P->kd_lo[(size_t)r].x, P->kd_lo[(size_t)r].y, P->kd_lo[(size_t)r].z};
+                const float hi3[3] = {P->kd_hi[(size_t)r].x, P->kd_hi[(size_t)r].y, P->kd_hi[(size_t)r].z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], lo3[a]); mx[a] = std::fmax(mx[a], hi3[a]); }
+            }
+            for (int a = 0; a < 3; ++a) { grid.chunk_lo[ci][a] = mn[a]; grid.chunk_hi[ci][a] = mx[a]; }
+            grid.chunk_lo[ci][3] = grid.chunk_hi[ci][3] = 0.f;
+        }
+    }
     {   // the two halves of the root split (the stack above splits [0, m) at k0 first; patches are whole on either side)
         int k0 = m;
         if (m > ICP_SUB) {

@@ -265,6 +265,26 @@ __device__ __forceinline__ void stage_chunk(const float4* __restrict__ tpl, cons
 // Per-wave query state: lane k of a wave holds query (wave + 16*k) of the slice.
 struct QueryRegs { float px, py, pz, pbest; int pbi, poi; };
 
+// Templates that do not fit LDS are searched chunk by chunk.  With a chunk table (IcpGrid: whole k-d subtrees, i.e. compact
+// regions, with their boxes) a workgroup stages a chunk only when its box comes within the running bound of SOME query of
+// the workgroup - once the cloud sits on the template a slice of neighbouring queries needs one or two chunks, not all.
+// Exact for the same reason as the run boxes: the chunk box's lower bound is below that of every run box inside it, so a
+// skipped chunk holds only runs that the search would have pruned.  Returns the wave's queries (lane mask) that need the
+// chunk; *any_in_wg says whether the workgroup needs it at all.  Contains two barriers: call from all threads.
+__device__ __forceinline__ unsigned long long chunk_needed(const IcpGrid& g, int ci, const QueryRegs& q, int nk, int* s_flag,
+                                                           bool* any_in_wg) {
+    const int lane = threadIdx.x & 63;
+    const float4 L = make_float4(g.chunk_lo[ci][0], g.chunk_lo[ci][1], g.chunk_lo[ci][2], 0.f);
+    const float4 H = make_float4(g.chunk_hi[ci][0], g.chunk_hi[ci][1], g.chunk_hi[ci][2], 0.f);
+    const unsigned long long m = ballot64(lane < nk && box_lb(L, H, q.px, q.py, q.pz) <= q.pbest);
+    if (threadIdx.x == 0) *s_flag = 0;
+    __syncthreads();
+    if (lane == 0 && m) atomicOr(s_flag, 1);
+    __syncthreads();
+    *any_in_wg = *s_flag != 0;
+    return m;
+}
+
 // Batched fetch of the wave's queries + seeds (one round of global loads per wave).
 // use_prev: seeds are the previous launch's neighbours (nn[]); coarse: also try the first point of
 // every run (worth its m/64 tests while the cloud still moves a lot between launches).
@@ -640,11 +660,11 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
                                                            const IcpCluster* __restrict__ cl, const IcpState* __restrict__ st,
                                                            unsigned long long* __restrict__ acc,
                                                            const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                           const float4* __restrict__ thi, float4* src, int* nn,
-                                                           float* d2buf, int qslice, int* queue) {
+                                                           const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
+                                                           float4* src, int* nn, float* d2buf, int qslice, int* queue) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned long long s_scr[8 * ICP_QSLICE];   // moment scratch, 8 terms at a time (32 KiB)
-    __shared__ int s_item[2];
+    __shared__ int s_item[3];   // [0], [1]: work items (double-buffered), [2]: chunk_needed flag
     const int lane = threadIdx.x & 63;
     RunBoxes bx;
     int staged = -1;   // template offset whose (single-chunk) image is resident in LDS
@@ -688,10 +708,21 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
             if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
             search_chunk(s_tpl, bx, 0, c.tpl_m, q, lanes_below(nk));
         } else {
-            for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
-                const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
-                stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
-                search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+            const IcpGrid& g = grids[c.slot];
+            if (g.nchunk > 0) {
+                for (int ci = 0; ci < g.nchunk; ++ci) {
+                    bool any;
+                    const unsigned long long todo = chunk_needed(g, ci, q, nk, &s_item[2], &any);
+                    if (!any) continue;
+                    stage_chunk(tp, blo, bhi, g.chunk_start[ci], g.chunk_n[ci], s_tpl, bx);
+                    search_chunk(s_tpl, bx, g.chunk_start[ci], g.chunk_n[ci], q, todo);
+                }
+            } else {
+                for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                    const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                    stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                    search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+                }
             }
             staged = -1;
         }
@@ -1277,11 +1308,12 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
                                                               const IcpState* __restrict__ st, int parity,
                                                               unsigned long long* __restrict__ accf,
                                                               const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                              const float4* __restrict__ thi, const float4* src0, int* nn,
-                                                              float* d2buf, int qslice) {
+                                                              const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
+                                                              const float4* src0, int* nn, float* d2buf, int qslice) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned long long s_acc;
     __shared__ float s_T[16];
+    __shared__ int s_flag;
     const IcpWork wk = work[blockIdx.x];
     const IcpCluster c = cl[wk.cluster];
     const IcpState* s = st + (size_t)wk.cluster * 2 + parity;
@@ -1302,10 +1334,21 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
         RunBoxes bx;
         int nk;
         fetch_queries(tp, c.tpl_m, src0 + c.src_off + q0, nq, true, false, true, T, nnq, q, nk);
-        for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
-            const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
-            stage_chunk(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c0, cn, s_tpl, bx);
-            search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+        const IcpGrid& g = grids[c.slot];
+        if (c.tpl_m > ICPT_TPL_LDS && g.nchunk > 0) {
+            for (int ci = 0; ci < g.nchunk; ++ci) {
+                bool any;
+                const unsigned long long todo = chunk_needed(g, ci, q, nk, &s_flag, &any);
+                if (!any) continue;
+                stage_chunk(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, g.chunk_start[ci], g.chunk_n[ci], s_tpl, bx);
+                search_chunk(s_tpl, bx, g.chunk_start[ci], g.chunk_n[ci], q, todo);
+            }
+        } else {
+            for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                stage_chunk(tp, tlo + c.tpl_off / ICP_SUB, thi + c.tpl_off / ICP_SUB, c0, cn, s_tpl, bx);
+                search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+            }
         }
         store_queries(q, nk, nnq, d2q);
     }
@@ -1321,19 +1364,19 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
 }
 
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
-                     unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
-                     int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm) {
+                     unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
+                     float4* src, int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm) {
     if (ncl <= 0) return;
     hipLaunchKernelGGL(k_icp_solve, dim3((ncl + WAVE - 1) / WAVE), dim3(WAVE), 0, s, it, ncl, cl, st, acc, queue, prm);
     if (n_work <= 0) return;   // every cluster converged: only the state bookkeeping above is needed
     hipLaunchKernelGGL(k_icp_iter, dim3(n_work < n_cu ? n_work : n_cu), dim3(ICPT_THREADS), 0, s, it, n_work, work, cl, st, acc, tpl, tlo,
-                       thi, src, nn, d2buf, qslice, queue);
+                       thi, grids, src, nn, d2buf, qslice, queue);
 }
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
-                        const float4* src0, int* nn, float* d2buf, int qslice) {
+                        const IcpGrid* grids, const float4* src0, int* nn, float* d2buf, int qslice) {
     if (n_work <= 0) return;
-    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(ICPT_THREADS), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, src0, nn, d2buf, qslice);
+    hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(ICPT_THREADS), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, grids, src0, nn, d2buf, qslice);
 }
 
 void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,

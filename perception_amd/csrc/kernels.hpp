@@ -56,11 +56,11 @@ void launch_label_scatter(hipStream_t s, const float4* obj, int N, int F, int T,
 
 // k_icp.hip
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
-                     unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, float4* src,
-                     int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm);
+                     unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
+                     float4* src, int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm);
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
-                        const float4* src0, int* nn, float* d2buf, int qslice);
+                        const IcpGrid* grids, const float4* src0, int* nn, float* d2buf, int qslice);
 
 void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
                      const float4* tpl, const float4* tlo, const float4* thi, const unsigned short* kdmap, const IcpGrid* grids,
