@@ -411,7 +411,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // Template groups: runs of clusters that share a template (one run per template when every cluster is matched against
     // every template).  With several templates in the batch, the groups whose template is LDS-resident and gridded go through
     // ONE k_icp_pipe launch (each group gets a share of the workgroups and its own queue) when there are enough of them to
-    // fill half the chip; the other clusters take the sliced driver below.
+    // fill a fifth of the chip; the other clusters take the sliced driver below.
     struct TplGroup { int beg, end, live; bool pipe; long long pts; };
     std::vector<TplGroup> groups;
     for (int k = 0; k < ncl; ++k) {
@@ -425,7 +425,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     int n_grouped = 0;
     for (const TplGroup& g : groups) if (g.pipe) n_grouped += g.live;
     const bool grouped_pipe = groups.size() > 1 && groups.size() <= 16 && n_grouped > 0 &&
-                              (c->icp_mode == 3 || (c->icp_mode == 0 && n_grouped >= c->n_cu / 2));
+                              (c->icp_mode == 3 || (c->icp_mode == 0 && n_grouped * 5 >= c->n_cu));
     if (std::getenv("CUBOID_DEBUG")) {
         std::fprintf(stderr, "cuboid_hip: stage_icp %d clusters, %zu template groups, %d in pipe groups, grouped_pipe %d:", ncl, groups.size(), n_grouped, (int)grouped_pipe);
         for (const TplGroup& g : groups) std::fprintf(stderr, " [%d,%d) m=%d pipe=%d live=%d", g.beg, g.end, c->h_cl[g.beg].tpl_m, (int)g.pipe, g.live);
@@ -464,7 +464,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     ip.rot_thr = 1.0 - p->icp_transformation_epsilon;
     ip.abs_mse = 1e-12;
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
-    // Batch mode: with at least ~n_cu/2 clusters every CU can own whole clusters, so each cluster runs its
+    // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
     // The pipelined variant (two clusters in flight per workgroup, no barrier in the iteration loop) needs one
     // LDS-resident gridded template shared by every cluster of the launch; otherwise k_icp_cluster runs.
@@ -472,7 +472,9 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     for (int k = 1; k < ncl && pipe_ok; ++k) pipe_ok = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
     // (auto mode: only the pipelined kernel beats the sliced driver; with mixed or non-resident templates k_icp_cluster's
     // barrier per iteration costs more than it saves, so those batches stay sliced unless the mode is forced)
-    const bool whole_cluster = !grouped_pipe && (c->icp_mode >= 2 || (c->icp_mode == 0 && ncl >= c->n_cu / 2 && pipe_ok));
+    // (measured crossover on the bench frames: 33 clusters 3.3 ms sliced / 3.7 ms pipelined, 65 clusters 4.4 / 3.9, 130 clusters
+    // 6.4 / 4.0: the pipelined kernel wins from about a fifth of the CUs' worth of clusters)
+    const bool whole_cluster = !grouped_pipe && (c->icp_mode >= 2 || (c->icp_mode == 0 && ncl * 5 >= c->n_cu && pipe_ok));
     if (grouped_pipe) {
         // items of `order`: the pipe groups one after the other, each largest cluster first
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
