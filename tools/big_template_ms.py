@@ -6,7 +6,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 big = pcd.read_xyz(os.path.join(R, "tests", "golden", "template_cuboid_L200_W100_H75.pcd")).astype(np.float32)
 print("template points", len(big))
 prm = capi.default_params(); prm.rgb_offset = 12
-for F in (1, 32):
+for F in ([int(a) for a in sys.argv[1:]] or [1, 32]):
     fr = np.stack([synth.frame(i) for i in range(F)], 0)
     ctx = capi.Context(max_points=fr.shape[1], max_frames=F)
     ctx.set_template(0, big)
