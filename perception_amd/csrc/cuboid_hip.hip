@@ -33,6 +33,8 @@ struct cd_context {
     // ordered-compaction tile counters
     int *d_tileA = nullptr, *d_tileB = nullptr, *d_tileK = nullptr;
     bool crop_two_pass = false;   // CUBOID_CROP_TWO_PASS=1: always the two-pass crop
+    int icp_persist = 1;          // CUBOID_ICP_PERSIST=0: the sliced driver always in its multi-launch form; 2: the persistent
+                                  // launch starts with its abort flag raised (tests the hand-over to the multi-launch form)
     // point buffers (float4 = x,y,z,rgb bits)
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_ghist = nullptr;
@@ -550,6 +552,52 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     }
     int it = 0;
     const int max_launch = p->icp_max_iterations + 3;
+    // Few clusters: ONE persistent launch runs every iteration and the fitness pass (k_icp_persist: grid barrier per
+    // iteration instead of two kernel launches).  Needs all its workgroups resident together; a barrier that does not
+    // complete in time makes it give up, and the multi-launch loop below takes over from the initial state.
+    if (nwork > 0 && c->icp_persist) {
+        const int G = std::min(nwork, c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu);
+        // measured against the multi-launch loop: 1 frame 1.50 / 1.78 ms, 4 frames 1.94 / 2.36, 8 frames 3.04 / 2.66 - with many
+        // clusters the launch lasts as long as the slowest one while finished workgroups wait at the barriers, and a workgroup
+        // with several items solves for each of them in turn
+        if (ncl <= 8 && nwork <= G) {
+            int n_open = 0;
+            for (int k = 0; k < ncl; ++k) if (c->h_cl[k].tile0 < (k + 1 < ncl ? c->h_cl[k + 1].tile0 : nwork)) ++n_open;
+            const int ctl[3] = {0, c->icp_persist == 2 ? 1 : 0, n_open};   // barrier counter, abort flag, clusters still iterating
+            HIPCHK(c, hipMemcpyAsync(c->d_queue + 4, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+            LAUNCH(c, launch_icp_persist(c->stream, nwork, G, max_launch, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid,
+                               c->d_src, c->d_src0, c->d_nn, c->d_d2, qslice, (unsigned*)(c->d_queue + 4), c->d_queue + 5, c->d_queue + 6, ip));
+            HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+            int gave_up = 0;
+            HIPCHK(c, hipMemcpyAsync(&gave_up, c->d_queue + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+            std::vector<IcpState> init(c->h_st, c->h_st + 2 * (size_t)ncl);   // in case the launch gave up
+            HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (!gave_up) {
+                float ms1 = 0.f;
+                hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
+                c->timing.icp_kernel_ms = ms1;
+                c->timing.icp_kernel_launches = 1;
+                if (pair_tests) {
+                    long long tot = 0;
+                    for (int k = 0; k < ncl; ++k)
+                        if (c->h_st[2 * k].status == CD_OK) tot += (long long)c->h_cl[k].n * c->h_cl[k].tpl_m * (c->h_st[2 * k].iters + 1);
+                    *pair_tests = tot;
+                }
+                return CD_OK;
+            }
+            if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: persistent ICP launch gave up at a grid barrier, running the multi-launch loop\n");
+            // start over: initial states, zero sums, the source points as extracted (the launch transformed them in place)
+            std::memcpy(c->h_st, init.data(), sizeof(IcpState) * 2 * (size_t)ncl);
+            HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
+            long long span = 0;
+            for (int k = 0; k < ncl; ++k) span = std::max(span, (long long)c->h_cl[k].src_off + c->h_cl[k].n);
+            HIPCHK(c, hipMemcpyAsync(c->d_src, c->d_src0, sizeof(float4) * (size_t)span, hipMemcpyDeviceToDevice, c->stream));
+        }
+    }
     // The iteration kernel walks an ACTIVE work list (d_work2) that the host re-packs at every
     // completion poll, dropping the clusters that have converged; the full list (d_work) is kept for
     // the fitness pass.  A cluster whose state shows done in either parity slot has already had its
@@ -1000,6 +1048,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;

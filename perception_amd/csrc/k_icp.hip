@@ -769,6 +769,259 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
 }
 
 // ---------------------------------------------------------------------------------------
+// Persistent form of the sliced driver (few clusters: one frame, small batches).  The multi-launch form above pays two
+// dependent kernel launches per PCL iteration (k_icp_solve, k_icp_iter: ~20 us together for one frame, most of it launch
+// turnaround); here ONE launch runs every iteration and the fitness pass:
+//   * work items (cluster, slice) are assigned statically, item i -> workgroup i % G, so a workgroup meets the same points
+//     in every iteration (no other workgroup ever reads them) and stages its template once;
+//   * the only data that crosses workgroups are the 16 moment sums of a cluster's correspondences: device-scope atomic adds
+//     into acc[cluster][it % 3], read back with device-scope atomic loads after a grid barrier (atomic arrive counter; the
+//     barrier inside a workgroup waits for its memory operations first, so no cache-flushing fence is needed);
+//   * every workgroup solves (Umeyama + convergence tests) for the clusters of its own items from those sums - a few
+//     redundant single-lane solves instead of a second barrier - and keeps their state in LDS; the workgroup that holds
+//     slice 0 of a cluster publishes it.
+// All G <= n_CU workgroups must be resident together (one per CU): they are, unless other kernels hold the CUs, in which
+// case the ones already running wait at the barrier.  Every wait is bounded (2^15 polls, some tens of milliseconds): a
+// barrier that does not complete raises the abort flag, every workgroup leaves, and the host runs the multi-launch form instead.
+// Same arithmetic as k_icp_solve + k_icp_iter + k_icp_fitness (the moments are order-free integer sums): identical results.
+// ---------------------------------------------------------------------------------------
+constexpr int PERSIST_ITEMS = 8;   // work items per workgroup at most
+
+__device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* abort_flag, int* s_ok) {
+    __syncthreads();   // s_waitcnt vmcnt(0): this workgroup's atomics and stores have been performed
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int ok = 1;
+        for (int spins = 0;; ++spins) {
+            if (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) break;
+            if (spins > (1 << 15) || __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        *s_ok = ok;
+    }
+    __syncthreads();
+    return *s_ok != 0;
+}
+
+// one PCL iteration's state update of a cluster from the moment sums of the previous iteration (what k_icp_solve does)
+__device__ void persist_solve(IcpState& so, const unsigned long long* A, int n, const IcpParams& prm) {
+    float T[16];
+    umeyama_from_moments(A, n, T);
+    float Tf[16];
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            Tf[4 * i + j] = ((T[4 * i] * so.Tfinal[j] + T[4 * i + 1] * so.Tfinal[4 + j]) + T[4 * i + 2] * so.Tfinal[8 + j]) +
+                            T[4 * i + 3] * so.Tfinal[12 + j];
+    for (int i = 0; i < 16; ++i) so.Tfinal[i] = Tf[i];
+    so.iters += 1;
+    int done = 0;
+    if (so.iters >= prm.max_iter) {
+        done = 1;
+    } else {
+        const double cos_angle = 0.5 * (double)(((T[0] + T[5]) + T[10]) - 1.0f);
+        const double translation_sqr = (double)((T[3] * T[3] + T[7] * T[7]) + T[11] * T[11]);
+        if (cos_angle >= prm.rot_thr && translation_sqr <= prm.trans_eps) {
+            done = 1;
+        } else {
+            const double mse = unfix(A[15], FIX_SHIFT_D2) / (double)n;
+            if (fabs(mse - so.prev_mse) < prm.abs_mse) done = 1;
+            else if (fabs(mse - so.prev_mse) / so.prev_mse < prm.rel_mse) done = 1;
+            so.prev_mse = mse;
+        }
+    }
+    so.done = done;
+    so.converged = done;
+    for (int i = 0; i < 16; ++i) so.T[i] = T[i];
+}
+
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int max_it, const IcpWork* __restrict__ work,
+                                                              const IcpCluster* __restrict__ cl, IcpState* st,
+                                                              unsigned long long* acc, unsigned long long* __restrict__ accf,
+                                                              const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                              const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
+                                                              float4* src, const float4* __restrict__ src0, int* nn, float* d2buf,
+                                                              int qslice, unsigned* bar, int* abort_flag, int* n_open, IcpParams prm) {
+    __shared__ float4 s_tpl[ICPT_IMG];
+    __shared__ unsigned long long s_scr[8 * ICP_QSLICE];   // moment scratch, 8 terms at a time (32 KiB)
+    __shared__ IcpState s_st[PERSIST_ITEMS];               // state of the clusters of this workgroup's items
+    __shared__ unsigned long long s_A[16];
+    __shared__ int s_flag, s_ok;
+    const int lane = threadIdx.x & 63;
+    const int G = gridDim.x;
+    int n_items = 0;
+    for (int i = blockIdx.x; i < n_work; i += G) ++n_items;   // <= PERSIST_ITEMS (host)
+    for (int j = threadIdx.x; j < n_items; j += ICPT_THREADS) s_st[j] = st[2 * (size_t)work[blockIdx.x + j * G].cluster];
+    __syncthreads();
+    RunBoxes bx;
+    int staged = -1;
+    bool aborted = false;
+    int it = 0;
+    for (; it < max_it; ++it) {
+        for (int j = 0; j < n_items; ++j) {
+            const IcpWork wk = work[blockIdx.x + j * G];
+            const IcpCluster c = cl[wk.cluster];
+            const bool was_done = s_st[j].done != 0;   // uniform: LDS value written before the last barrier
+            if (was_done) continue;
+            if (it > 0) {   // this iteration's transformation from the previous iteration's correspondences
+                if (threadIdx.x < 16)
+                    s_A[threadIdx.x] = __hip_atomic_load(acc + ((size_t)wk.cluster * 3 + (it - 1) % 3) * 16 + threadIdx.x, __ATOMIC_RELAXED,
+                                                         __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    IcpState so = s_st[j];
+                    persist_solve(so, s_A, c.n, prm);
+                    s_st[j] = so;
+                    if (wk.tile == 0 && so.done) atomicSub(n_open, 1);
+                }
+                __syncthreads();
+            }
+            if (wk.tile == 0 && threadIdx.x < 16)   // the sums of iteration it + 1 start from zero (slot last read in iteration it - 1)
+                __hip_atomic_store(acc + ((size_t)wk.cluster * 3 + (it + 1) % 3) * 16 + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int done_now = s_st[j].done;
+            const int q0 = wk.tile * qslice;
+            const int nq = min(qslice, c.n - q0);
+            float4* pts = src + c.src_off + q0;
+            int* nnq = nn + c.src_off + q0;
+            float* d2q = d2buf + c.src_off + q0;
+            if (it > 0) {   // X <- T * X, in place
+                float T[12];
+#pragma unroll
+                for (int k = 0; k < 12; ++k) T[k] = s_st[j].T[k];
+                for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) {
+                    const float4 p = pts[i];
+                    float ox, oy, oz;
+                    xform(T, p.x, p.y, p.z, ox, oy, oz);
+                    pts[i] = make_float4(ox, oy, oz, p.w);
+                }
+            }
+            if (done_now) continue;
+            __syncthreads();   // the transformed points are read by other waves below
+            const float4* tp = tpl + c.tpl_off;
+            const float4* blo = tlo + c.tpl_off / ICP_SUB;
+            const float4* bhi = thi + c.tpl_off / ICP_SUB;
+            QueryRegs q;
+            int nk;
+            fetch_queries(tp, c.tpl_m, pts, nq, it > 0, it < 3, false, nullptr, nnq, q, nk);
+            if (c.tpl_m <= ICPT_TPL_LDS) {
+                if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
+                search_chunk(s_tpl, bx, 0, c.tpl_m, q, lanes_below(nk));
+            } else {
+                const IcpGrid& g = grids[c.slot];
+                if (g.nchunk > 0) {
+                    for (int ci = 0; ci < g.nchunk; ++ci) {
+                        bool any;
+                        const unsigned long long todo = chunk_needed(g, ci, q, nk, &s_flag, &any);
+                        if (!any) continue;
+                        stage_chunk(tp, blo, bhi, g.chunk_start[ci], g.chunk_n[ci], s_tpl, bx);
+                        search_chunk(s_tpl, bx, g.chunk_start[ci], g.chunk_n[ci], q, todo);
+                    }
+                } else {
+                    for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                        const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                        stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                        search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+                    }
+                }
+                staged = -1;
+            }
+            store_queries(q, nk, nnq, d2q);
+            __syncthreads();
+            unsigned long long S[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) S[k] = 0ull;
+            if (threadIdx.x < nq) {
+                const int i = threadIdx.x;
+                const float4 p = pts[i];
+                const float4 qq = tp[nnq[i]];
+                const float pv[3] = {p.x, p.y, p.z}, qv[3] = {qq.x, qq.y, qq.z};
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                    S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                    for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                }
+                S[15] = (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (h) __syncthreads();
+                if (threadIdx.x < ICP_QSLICE) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s_scr[k * ICP_QSLICE + threadIdx.x] = S[8 * h + k];
+                }
+                __syncthreads();
+                const int k = threadIdx.x >> 6;   // waves 0..7 <-> the 8 moments of this half
+                if (k < 8) {
+                    unsigned long long t = 0ull;
+#pragma unroll
+                    for (int jj = 0; jj < ICP_QSLICE / 64; ++jj) t += s_scr[k * ICP_QSLICE + jj * 64 + lane];
+                    t = wave_sum_u64(t);
+                    if (lane == 0) atomicAdd(&acc[((size_t)wk.cluster * 3 + it % 3) * 16 + 8 * h + k], t);
+                }
+            }
+            __syncthreads();   // s_scr is reused by the next item
+        }
+        if (!grid_barrier(bar, (unsigned)(it + 1) * (unsigned)G, abort_flag, &s_ok)) { aborted = true; break; }
+        if (__hip_atomic_load(n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) { ++it; break; }
+    }
+    if (aborted) return;
+    // fitness pass (what k_icp_fitness does) and publication of the states
+    for (int j = 0; j < n_items; ++j) {
+        const IcpWork wk = work[blockIdx.x + j * G];
+        const IcpCluster c = cl[wk.cluster];
+        if (wk.tile == 0 && threadIdx.x == 0) { st[2 * (size_t)wk.cluster] = s_st[j]; st[2 * (size_t)wk.cluster + 1] = s_st[j]; }
+        if (s_st[j].status != CD_OK) continue;
+        float T[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) T[k] = s_st[j].Tfinal[k];
+        const int q0 = wk.tile * qslice;
+        const int nq = min(qslice, c.n - q0);
+        int* nnq = nn + c.src_off + q0;
+        float* d2q = d2buf + c.src_off + q0;
+        const float4* tp = tpl + c.tpl_off;
+        const float4* blo = tlo + c.tpl_off / ICP_SUB;
+        const float4* bhi = thi + c.tpl_off / ICP_SUB;
+        __syncthreads();
+        QueryRegs q;
+        int nk;
+        fetch_queries(tp, c.tpl_m, src0 + c.src_off + q0, nq, true, false, true, T, nnq, q, nk);
+        if (c.tpl_m <= ICPT_TPL_LDS) {
+            if (staged != c.tpl_off) { stage_chunk(tp, blo, bhi, 0, c.tpl_m, s_tpl, bx); staged = c.tpl_off; }
+            search_chunk(s_tpl, bx, 0, c.tpl_m, q, lanes_below(nk));
+        } else {
+            const IcpGrid& g = grids[c.slot];
+            if (g.nchunk > 0) {
+                for (int ci = 0; ci < g.nchunk; ++ci) {
+                    bool any;
+                    const unsigned long long todo = chunk_needed(g, ci, q, nk, &s_flag, &any);
+                    if (!any) continue;
+                    stage_chunk(tp, blo, bhi, g.chunk_start[ci], g.chunk_n[ci], s_tpl, bx);
+                    search_chunk(s_tpl, bx, g.chunk_start[ci], g.chunk_n[ci], q, todo);
+                }
+            } else {
+                for (int c0 = 0; c0 < c.tpl_m; c0 += ICPT_TPL_LDS) {
+                    const int cn = min(ICPT_TPL_LDS, c.tpl_m - c0);
+                    stage_chunk(tp, blo, bhi, c0, cn, s_tpl, bx);
+                    search_chunk(s_tpl, bx, c0, cn, q, lanes_below(nk));
+                }
+            }
+            staged = -1;
+        }
+        store_queries(q, nk, nnq, d2q);
+        __syncthreads();
+        unsigned long long v = 0ull;
+        for (int i = threadIdx.x; i < nq; i += ICPT_THREADS) v += (unsigned long long)fixq(d2q[i], FIX_SHIFT_D2);
+        v = wave_sum_u64(v);
+        if (lane == 0 && v) atomicAdd(&accf[wk.cluster], v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Whole-cluster variant (batch mode): ONE persistent workgroup takes a cluster from the queue
 // (largest first) and runs its complete ICP - every iteration's transform, search, moments,
 // Umeyama/SVD solve and convergence test, then the fitness pass - without leaving the CU.
@@ -1377,6 +1630,15 @@ void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const Ic
                         const IcpGrid* grids, const float4* src0, int* nn, float* d2buf, int qslice) {
     if (n_work <= 0) return;
     hipLaunchKernelGGL(k_icp_fitness, dim3(n_work), dim3(ICPT_THREADS), 0, s, work, cl, st, parity, accf, tpl, tlo, thi, grids, src0, nn, d2buf, qslice);
+}
+
+void launch_icp_persist(hipStream_t s, int n_work, int n_wg, int max_it, const IcpWork* work, const IcpCluster* cl, IcpState* st,
+                         unsigned long long* acc, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
+                         const IcpGrid* grids, float4* src, const float4* src0, int* nn, float* d2buf, int qslice, unsigned* bar,
+                         int* abort_flag, int* n_open, IcpParams prm) {
+    if (n_work <= 0 || n_wg <= 0) return;
+    hipLaunchKernelGGL(k_icp_persist, dim3(n_wg), dim3(ICPT_THREADS), 0, s, n_work, max_it, work, cl, st, acc, accf, tpl, tlo, thi, grids,
+                       src, src0, nn, d2buf, qslice, bar, abort_flag, n_open, prm);
 }
 
 void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,

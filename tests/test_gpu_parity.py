@@ -292,6 +292,30 @@ def test_extract_indices_keeps_whole_records(ctx, O, frames4):
         ctx.extract(rec, np.array([2049], np.int32), negative=False)
 
 
+def test_persistent_sliced_kernel_equals_multi_launch(template, frames4, monkeypatch):
+    """One frame / a few clusters: ONE persistent launch with a grid barrier per iteration (k_icp_persist) against the
+    multi-launch loop (k_icp_solve + k_icp_iter per iteration, then k_icp_fitness): identical records."""
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    out = {}
+    for persist in ("1", "0", "2"):   # 2: the persistent launch gives up at its first barrier, the multi-launch loop takes over
+        monkeypatch.setenv("CUBOID_ICP_PERSIST", persist)
+        monkeypatch.setenv("CUBOID_ICP_MODE", "sliced")
+        c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=4)
+        try:
+            c.set_template(0, template)
+            recs = []
+            for f in range(4):
+                r, _, _ = c.process_frame(frames4[f], prm)
+                recs.append(bytes(r))
+            rb, _, _ = c.process_batch(np.stack(frames4[:3], 0), prm)      # 5 clusters, still one launch
+            out[persist] = (recs, bytes(capi.results_to_array(rb).tobytes()), c.timing().icp_kernel_launches)
+        finally:
+            c.close()
+    assert out["1"][0] == out["0"][0] == out["2"][0] and out["1"][1] == out["0"][1] == out["2"][1]
+    assert out["1"][2] == 1 and out["0"][2] > 10 and out["2"][2] > 10
+
+
 def test_process_frame_is_a_batch_of_one(ctx, frames4):
     prm = capi.default_params()
     prm.rgb_offset = 12
