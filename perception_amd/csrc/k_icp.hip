@@ -838,6 +838,18 @@ __device__ void persist_solve(IcpState& so, const unsigned long long* A, int n, 
     for (int i = 0; i < 16; ++i) so.T[i] = T[i];
 }
 
+#ifdef CD_PERSISTDBG
+// time workgroup 0 spends per phase of an iteration (100 MHz ticks): solve, transform, fetch + search + store, moments, barrier
+__device__ unsigned long long g_persist_dbg[8];
+extern "C" int cd_debug_persist(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_persist_dbg), sizeof(g_persist_dbg)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[8]; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_persist_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define PERSIST_PHASE(k) { __syncthreads(); if (blockIdx.x == 0 && threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); g_persist_dbg[k] += t_ - tdbg_; tdbg_ = t_; } }
+#else
+#define PERSIST_PHASE(k)
+#endif
 __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int max_it, const IcpWork* __restrict__ work,
                                                               const IcpCluster* __restrict__ cl, IcpState* st,
                                                               unsigned long long* acc, unsigned long long* __restrict__ accf,
@@ -859,6 +871,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
     RunBoxes bx;
     int staged = -1;
     bool aborted = false;
+#ifdef CD_PERSISTDBG
+    unsigned long long tdbg_ = wall_clock64();
+#endif
     int it = 0;
     for (; it < max_it; ++it) {
         for (int j = 0; j < n_items; ++j) {
@@ -879,6 +894,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
                 }
                 __syncthreads();
             }
+            PERSIST_PHASE(0)
             if (wk.tile == 0 && threadIdx.x < 16)   // the sums of iteration it + 1 start from zero (slot last read in iteration it - 1)
                 __hip_atomic_store(acc + ((size_t)wk.cluster * 3 + (it + 1) % 3) * 16 + threadIdx.x, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int done_now = s_st[j].done;
@@ -900,6 +916,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
             }
             if (done_now) continue;
             __syncthreads();   // the transformed points are read by other waves below
+            PERSIST_PHASE(1)
             const float4* tp = tpl + c.tpl_off;
             const float4* blo = tlo + c.tpl_off / ICP_SUB;
             const float4* bhi = thi + c.tpl_off / ICP_SUB;
@@ -930,6 +947,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
             }
             store_queries(q, nk, nnq, d2q);
             __syncthreads();
+            PERSIST_PHASE(2)
             unsigned long long S[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) S[k] = 0ull;
@@ -965,8 +983,10 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
                 }
             }
             __syncthreads();   // s_scr is reused by the next item
+            PERSIST_PHASE(3)
         }
         if (!grid_barrier(bar, (unsigned)(it + 1) * (unsigned)G, abort_flag, &s_ok)) { aborted = true; break; }
+        PERSIST_PHASE(4)
         if (__hip_atomic_load(n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) { ++it; break; }
     }
     if (aborted) return;
