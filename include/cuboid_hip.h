@@ -253,6 +253,8 @@ typedef struct cd_timing {
     float icp_kernel_ms;
     int32_t icp_kernel_launches;
     int32_t icp_pair_tests_lo, icp_pair_tests_hi; /* 64-bit count of point-pair distance tests */
+    int32_t icp_persist_gave_up;                  /* single-launch ICPs of this call that gave up at a grid barrier and were redone by the
+                                                   * multi-launch loop (same results, tens of ms slower): 0 in a healthy run           */
     int64_t algorithmic_bytes;                    /* B_alg of SURVEY 8(d) for this batch */
     int64_t icp_algorithmic_bytes;                /* the S6 term of B_alg: sum 12*M + 12*N_s*(I_c+1) */
 } cd_timing;

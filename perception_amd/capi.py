@@ -87,7 +87,7 @@ class CdTiming(C.Structure):
     _fields_ = [
         ("stage_ms", C.c_float * 5), ("icp_kernel_ms", C.c_float),
         ("icp_kernel_launches", C.c_int32),
-        ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32),
+        ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32), ("icp_persist_gave_up", C.c_int32),
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
     ]
 

@@ -60,6 +60,10 @@ struct cd_context {
     float* d_d2 = nullptr;                                        // its squared distance
     int* d_queue = nullptr;                                       // ICP work queue heads (one per template group)
     int* d_wgtab = nullptr;                                       // k_icp_pipe: {first item, end item, queue} per workgroup
+    int* h_wgtab = nullptr;                                       // its pinned staging copy (3 * 1024 ints)
+    int* h_ctl = nullptr;                                         // pinned: control words of k_icp_persist going up [0..7], coming back [8]
+    std::vector<IcpState> st_init;                                // initial ICP states of a persistent launch (kept in case it gives up)
+    int persist_gave_up = 0;                                      // persistent launches of this context that handed over to the multi-launch loop
     int n_cu = 256;
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
@@ -480,7 +484,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     if (grouped_pipe) {
         // items of `order`: the pipe groups one after the other, each largest cluster first
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
-        std::vector<int> tab;
+        int* tab = c->h_wgtab;   // pinned: the copy below is asynchronous
+        int ntab = 0;
         long long pts_all = 0;
         int npg = 0;
         for (const TplGroup& g : groups) if (g.pipe && g.live > 0) { pts_all += g.pts; ++npg; }
@@ -493,17 +498,16 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             // workgroups in proportion to the group's points, at least one, no more than it has clusters
             int share = (int)((long long)wg_cap * g.pts / std::max(pts_all, 1ll));
             share = std::max(1, std::min(share, std::min(g.live, wg_cap - n_wg - (npg - 1 - gq))));
-            for (int w = 0; w < share; ++w) { tab.push_back(b); tab.push_back(no); tab.push_back(gq); }
+            for (int w = 0; w < share && ntab + 3 <= 3 * 1024; ++w) { tab[ntab++] = b; tab[ntab++] = no; tab[ntab++] = gq; }
             n_wg += share;
             ++gq;
         }
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
         LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                         c->d_queue, n_wg, c->d_wgtab, ip));
         c->timing.icp_kernel_launches = 1;
-        // `tab` must outlive the copy: the sliced part below (or the read-back) synchronises the stream before it goes away
         if (nwork == 0) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
@@ -563,17 +567,21 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         if (ncl <= 8 && nwork <= G) {
             int n_open = 0;
             for (int k = 0; k < ncl; ++k) if (c->h_cl[k].tile0 < (k + 1 < ncl ? c->h_cl[k + 1].tile0 : nwork)) ++n_open;
-            const int ctl[3] = {0, c->icp_persist == 2 ? 1 : 0, n_open};   // barrier counter, abort flag, clusters still iterating
-            HIPCHK(c, hipMemcpyAsync(c->d_queue + 4, ctl, sizeof(ctl), hipMemcpyHostToDevice, c->stream));
+            // d_queue[4] barrier counter, [5] abort flag, [6..9] clusters closed per iteration slot (k_icp_persist's exit test)
+            int* ctl = c->h_ctl;
+            for (int i = 0; i < 8; ++i) ctl[i] = 0;
+            ctl[1] = c->icp_persist == 2 ? 1 : 0;
+            HIPCHK(c, hipMemcpyAsync(c->d_queue + 4, ctl, sizeof(int) * 6, hipMemcpyHostToDevice, c->stream));
             LAUNCH(c, launch_icp_persist(c->stream, nwork, G, max_launch, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid,
-                               c->d_src, c->d_src0, c->d_nn, c->d_d2, qslice, (unsigned*)(c->d_queue + 4), c->d_queue + 5, c->d_queue + 6, ip));
+                               c->d_src, c->d_src0, c->d_nn, c->d_d2, qslice, (unsigned*)(c->d_queue + 4), c->d_queue + 5, n_open, c->d_queue + 6, ip));
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            int gave_up = 0;
-            HIPCHK(c, hipMemcpyAsync(&gave_up, c->d_queue + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(ctl + 8, c->d_queue + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
-            std::vector<IcpState> init(c->h_st, c->h_st + 2 * (size_t)ncl);   // in case the launch gave up
+            c->st_init.assign(c->h_st, c->h_st + 2 * (size_t)ncl);   // in case the launch gives up (no reallocation after the first call)
+            std::vector<IcpState>& init = c->st_init;
             HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
+            const int gave_up = ctl[8];
             if (!gave_up) {
                 float ms1 = 0.f;
                 hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -587,6 +595,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
                 }
                 return CD_OK;
             }
+            c->persist_gave_up += 1;
+            c->timing.icp_persist_gave_up += 1;
             if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: persistent ICP launch gave up at a grid barrier, running the multi-launch loop\n");
             // start over: initial states, zero sums, the source points as extracted (the launch transformed them in place)
             std::memcpy(c->h_st, init.data(), sizeof(IcpState) * 2 * (size_t)ncl);
@@ -786,6 +796,9 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     if (p->template_slot >= 0) slots.push_back(p->template_slot);
     else for (int sidx = 0; sidx < CD_MAX_TEMPLATES; ++sidx) if (c->tpl_m[sidx] > 0) slots.push_back(sidx);
     if (slots.empty()) slots.push_back(0);
+    // (the per-cluster results of the previous batch go away here: last_first stays empty until this batch has succeeded,
+    // so a failure in between leaves cd_get_cluster_results with "no batch" rather than old offsets into new results)
+    c->last_first.clear();
     std::vector<cd_cluster_result>& best = c->last_clusters;
     best.assign((size_t)std::max(ncl, 1), cd_cluster_result());
     long long pairs = 0;
@@ -990,7 +1003,7 @@ void cd_destroy(cd_context* c) {
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     if (c->d_koffx) hipFree(c->d_koffx);
-    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
+    void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf, c->h_wgtab, c->h_ctl};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -1037,6 +1050,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_kdmap, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tplk, (size_t)c->tpl_cap) == hipSuccess && dalloc(&c->d_tlok, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thik, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)16) == hipSuccess && dalloc(&c->d_wgtab, (size_t)3 * 1024) == hipSuccess;
+    ok = ok && halloc(&c->h_wgtab, (size_t)3 * 1024) == hipSuccess && halloc(&c->h_ctl, (size_t)16) == hipSuccess;
     {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, device_id) == hipSuccess && prop.multiProcessorCount > 0) c->n_cu = prop.multiProcessorCount;
@@ -1645,6 +1659,7 @@ int cd_get_cluster_results(const cd_context* c, int frame, int first, int capaci
     if (frame < 0 || first < 0 || capacity < 0 || (capacity > 0 && !out)) return CD_ERR_INVALID_ARG;
     if ((size_t)frame + 1 >= c->last_first.size()) return CD_ERR_INVALID_ARG;   // not a frame of the last batch
     const int lo = c->last_first[(size_t)frame], hi = c->last_first[(size_t)frame + 1];
+    if (lo < 0 || hi < lo || (size_t)hi > c->last_clusters.size()) return CD_ERR_INVALID_ARG;
     if (out_total) *out_total = hi - lo;
     int n = 0;
     for (int k = lo + first; k < hi && n < capacity; ++k) out[n++] = c->last_clusters[(size_t)k];

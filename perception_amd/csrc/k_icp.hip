@@ -787,8 +787,16 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_iter(int it, int n_work, c
 // ---------------------------------------------------------------------------------------
 constexpr int PERSIST_ITEMS = 8;   // work items per workgroup at most
 
+// What crosses workgroups in k_icp_persist are agent-scope atomics only (moment adds, zero-stores, the counters below):
+// they are performed at the device's coherence point, so no cache write-back is needed - but they must have been
+// PERFORMED before this workgroup counts as arrived.  __syncthreads() alone does not give that on gfx950 (the backend
+// emits s_waitcnt lgkmcnt(0) + s_barrier: a workgroup-scope fence does not wait for vector-memory operations outside
+// tgsplit mode), so every thread first waits for its own outstanding vector-memory operations (gfx9 counts loads, stores
+// and atomics without return in vmcnt alike).  The points / neighbour arrays a workgroup writes with plain stores are only
+// ever read back by the same workgroup, hence no agent-scope release fence (which would write the L2 back every iteration).
 __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int* abort_flag, int* s_ok) {
-    __syncthreads();   // s_waitcnt vmcnt(0): this workgroup's atomics and stores have been performed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     if (threadIdx.x == 0) {
         __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int ok = 1;
@@ -803,7 +811,8 @@ __device__ __forceinline__ bool grid_barrier(unsigned* bar, unsigned target, int
         }
         *s_ok = ok;
     }
-    __syncthreads();
+    __syncthreads();   // everything after it is issued after thread 0 saw the full count (loads are not hoisted over s_barrier)
+    asm volatile("" ::: "memory");
     return *s_ok != 0;
 }
 
@@ -856,7 +865,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
                                                               const float4* __restrict__ tpl, const float4* __restrict__ tlo,
                                                               const float4* __restrict__ thi, const IcpGrid* __restrict__ grids,
                                                               float4* src, const float4* __restrict__ src0, int* nn, float* d2buf,
-                                                              int qslice, unsigned* bar, int* abort_flag, int* n_open, IcpParams prm) {
+                                                              int qslice, unsigned* bar, int* abort_flag, int n_open, int* closed, IcpParams prm) {
     __shared__ float4 s_tpl[ICPT_IMG];
     __shared__ unsigned long long s_scr[8 * ICP_QSLICE];   // moment scratch, 8 terms at a time (32 KiB)
     __shared__ IcpState s_st[PERSIST_ITEMS];               // state of the clusters of this workgroup's items
@@ -875,6 +884,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
     unsigned long long tdbg_ = wall_clock64();
 #endif
     int it = 0;
+    int seen0 = 0, seen1 = 0, seen2 = 0, seen3 = 0;   // closed[0..3] as last read
     for (; it < max_it; ++it) {
         for (int j = 0; j < n_items; ++j) {
             const IcpWork wk = work[blockIdx.x + j * G];
@@ -890,7 +900,8 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
                     IcpState so = s_st[j];
                     persist_solve(so, s_A, c.n, prm);
                     s_st[j] = so;
-                    if (wk.tile == 0 && so.done) atomicSub(n_open, 1);
+                    // one count per cluster that closes in iteration `it`, into the slot of that iteration (see the exit test)
+                    if (wk.tile == 0 && so.done) __hip_atomic_fetch_add(closed + (it & 3), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 __syncthreads();
             }
@@ -987,7 +998,18 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_persist(int n_work, int ma
         }
         if (!grid_barrier(bar, (unsigned)(it + 1) * (unsigned)G, abort_flag, &s_ok)) { aborted = true; break; }
         PERSIST_PHASE(4)
-        if (__hip_atomic_load(n_open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= 0) { ++it; break; }
+        // Exit when every cluster has closed - decided from state that is FINAL at this barrier: closed[it & 3] only receives
+        // the closes of iterations it, it - 4, ... (a workgroup that runs ahead adds to slot (it + 1) & 3, and slot it & 3 is
+        // next written in iteration it + 4, which nobody enters before all have left barrier it + 3), and every workgroup
+        // reads slot it & 3 between barrier it and its arrival at barrier it + 1.  All workgroups therefore see the same
+        // running total and leave in the same iteration.  (A single shared count of open clusters was read "from the
+        // future": a slower workgroup could see the zero a faster one produced one iteration later and leave early.)
+        {
+            const int v = __hip_atomic_load(closed + (it & 3), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen0 = (it & 3) == 0 ? v : seen0; seen1 = (it & 3) == 1 ? v : seen1;
+            seen2 = (it & 3) == 2 ? v : seen2; seen3 = (it & 3) == 3 ? v : seen3;
+        }
+        if (seen0 + seen1 + seen2 + seen3 >= n_open) { ++it; break; }
     }
     if (aborted) return;
     // fitness pass (what k_icp_fitness does) and publication of the states
@@ -1655,10 +1677,10 @@ void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const Ic
 void launch_icp_persist(hipStream_t s, int n_work, int n_wg, int max_it, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                          unsigned long long* acc, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
                          const IcpGrid* grids, float4* src, const float4* src0, int* nn, float* d2buf, int qslice, unsigned* bar,
-                         int* abort_flag, int* n_open, IcpParams prm) {
+                         int* abort_flag, int n_open, int* closed, IcpParams prm) {
     if (n_work <= 0 || n_wg <= 0) return;
     hipLaunchKernelGGL(k_icp_persist, dim3(n_wg), dim3(ICPT_THREADS), 0, s, n_work, max_it, work, cl, st, acc, accf, tpl, tlo, thi, grids,
-                       src, src0, nn, d2buf, qslice, bar, abort_flag, n_open, prm);
+                       src, src0, nn, d2buf, qslice, bar, abort_flag, n_open, closed, prm);
 }
 
 void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,

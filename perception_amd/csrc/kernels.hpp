@@ -61,7 +61,7 @@ void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* 
 void launch_icp_persist(hipStream_t s, int n_work, int n_wg, int max_it, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                          unsigned long long* acc, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
                          const IcpGrid* grids, float4* src, const float4* src0, int* nn, float* d2buf, int qslice, unsigned* bar,
-                         int* abort_flag, int* n_open, IcpParams prm);
+                         int* abort_flag, int n_open, int* closed, IcpParams prm);
 void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const IcpCluster* cl, const IcpState* st,
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
                         const IcpGrid* grids, const float4* src0, int* nn, float* d2buf, int qslice);
