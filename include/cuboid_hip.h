@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CD_ABI_VERSION 2
+#define CD_ABI_VERSION 3
 #define CD_MAX_TEMPLATES 8          /* template slots per context (BASELINE config 5 uses 5) */
 #define CD_MAX_CLUSTERS_PER_FRAME 8 /* cluster slots in the fixed-size per-frame record; a frame with more clusters still
                                      * gets an ICP for every one of them (opd.cpp:376): see cd_get_cluster_results       */
@@ -102,7 +102,19 @@ typedef struct cd_params {
     int32_t plane_model;
     float plane_axis[3];
     double plane_eps_angle;             /* radians; sne.cpp:123 uses 0.1 */
+    /* Initial guess of the registration: pcl::Registration::align(output, guess).  The reference's live path calls
+     * align(output) - the identity guess - and that is the default here (CD_GUESS_NONE).  Its authors meant to start from
+     * the pose surface_normal_estimation publishes (icp.cpp:130-134 stores it, :165-167 moves the template by it; both
+     * commented out / inert, and iterative_closest_point.launch:17-18 leaves the sne node out), so the guess is opt-in:
+     * CD_GUESS_PARAMS uses icp_guess for every ICP of the call, CD_GUESS_PER_FRAME the matrix cd_set_frame_guesses stored
+     * for the cluster's frame.  PCL semantics: the source is first moved by the guess (input_transformed = guess * source,
+     * float32 4x4 * point), final_transformation_ starts as the guess, the iterations and the convergence tests run on the
+     * moved cloud, getFinalTransformation() includes the guess and getFitnessScore() is that of final * source. */
+    int32_t icp_use_guess;
+    float icp_guess[16];                /* row-major, scene -> template */
 } cd_params;
+
+enum { CD_GUESS_NONE = 0, CD_GUESS_PARAMS = 1, CD_GUESS_PER_FRAME = 2 };
 
 enum { CD_PLANE = 0, CD_PLANE_PERPENDICULAR = 1, CD_PLANE_PARALLEL = 2 };
 
@@ -228,6 +240,45 @@ int cd_process_frame(cd_context* ctx, const void* points, size_t stride_bytes, i
  * receives the number of clusters of that frame.  Returns the number of results copied, or a negative cd_status. */
 int cd_get_cluster_results(const cd_context* ctx, int frame, int first, int capacity, cd_cluster_result* out,
                            int* out_total);
+
+/* What the reference's nodes publish besides poses are CLOUDS of the frame they just processed; after a fused call those
+ * are still resident on the device and are read back here (last cd_process_batch* / cd_process_frame call of this context;
+ * any other compute call of the context invalidates them: CD_ERR_INVALID_ARG).
+ *
+ * cd_get_frame_cloud: which = CD_CLOUD_VOXELS, the VoxelGrid output (gps.cpp:73, opd.cpp:298); CD_CLOUD_OBJECTS, what is left
+ * after the plane has been taken out (ExtractIndices, gps.cpp:96-101) and the second z crop - the cloud object_pose_detection
+ * publishes on its <output> topic (opd.cpp:331-343).  Records are written in a PointCloud2 layout of the caller's choice:
+ * `stride_bytes` (a multiple of 4, >= 12) per point, x,y,z float32 at byte offsets 0/4/8, the averaged packed colour at
+ * rgb_offset (-1: none; a multiple of 4, >= 12), every other byte zero - with the INPUT's point_step and rgb offset this is
+ * what fromPCL(ExtractIndices<PCLPointCloud2>(VoxelGrid<PCLPointCloud2>(input))) hands to the publisher. */
+enum { CD_CLOUD_VOXELS = 0, CD_CLOUD_OBJECTS = 1 };
+int cd_get_frame_cloud(cd_context* ctx, int frame, int which, void* out_records, size_t stride_bytes, int rgb_offset,
+                       int capacity, int* out_n);
+
+/* The points of cluster k (rank order, as in cd_get_cluster_results) of `frame`: aligned == 0 the cluster as extracted
+ * (ExtractIndices of opd.cpp:378-387), aligned != 0 the cloud icp.align(output) returned for it (opd.cpp:228, the cloud
+ * behind /icp/registered_pcl, opd.cpp:259-262; icp.cpp:178,193 -> /icp/aligned_points).  Records of `stride_bytes`
+ * (multiple of 4, >= 12): x,y,z at 0/4/8; with stride_bytes >= 16 the fourth word is 1.0f, which is what pcl::PointXYZ holds
+ * there and pcl::toROSMsg(PointCloud<PointXYZ>) puts on the wire (point_step 16); further bytes zero.
+ * (When several templates were matched in separate passes and the best one was not the last, the aligned cloud is
+ * final_transformation * cluster evaluated once, not the iterated cloud - equal up to float32 rounding.) */
+int cd_get_cluster_points(cd_context* ctx, int frame, int k, int aligned, void* out_points, size_t stride_bytes,
+                          int capacity, int* out_n);
+
+/* The body of ground_plane_segmentation's callback (gps.cpp:43-112) as ONE call: two PassThrough filters, VoxelGrid,
+ * SACSegmentation, ExtractIndices - one upload of the PointCloud2 blob, one download of the cloud to publish.
+ * out_records receives the kept voxels in the INPUT's record layout (stride_bytes per record, centroid at 0/4/8, averaged
+ * colour at prm->rgb_offset, other bytes zero), *out_n their number, coeff the refined plane, *out_n_inliers the size of
+ * the refined inlier set.  prm->crop2_enable / bbox_enable apply as in the fused chain (the gps node sets both 0).
+ * When RANSAC finds no plane the status is CD_ERR_NO_MODEL, coeff is untouched and the records are what PCL's
+ * ExtractIndices yields for an empty index list (negative: every voxel; otherwise none), as gps.cpp:93-107 publishes. */
+int cd_ground_plane(cd_context* ctx, const void* points, size_t stride_bytes, int n, const cd_params* prm, float coeff[4],
+                    void* out_records, int capacity, int* out_n, int* out_n_inliers);
+
+/* Per-frame initial guesses for cd_params.icp_use_guess == CD_GUESS_PER_FRAME: n_frames row-major 4x4 float32 matrices
+ * (scene -> template), frame f of the following cd_process_batch* calls uses guesses[16 f .. 16 f + 15] for each of its
+ * clusters (the granularity of the reference: one sne pose per frame, icp.cpp:130-134).  n_frames = 0 clears them. */
+int cd_set_frame_guesses(cd_context* ctx, const float* guesses, int n_frames);
 
 /* Same, input already resident in device memory (HBM) of the context's GPU.  A context works on its own
  * non-blocking HIP stream: there is no implicit ordering against the NULL stream or any other stream, so the

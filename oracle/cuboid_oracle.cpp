@@ -950,15 +950,27 @@ struct IcpOut {
     std::vector<float> aligned;
 };
 
+// guess (may be NULL = identity, the reference's live path): pcl::Registration::align(output, guess) followed by
+// IterativeClosestPoint::computeTransformation - final_transformation_ = guess; if (guess != Identity)
+// transformPointCloud(*input_, *input_transformed, guess) (float32, ((a x + b y) + c z) + d per row); the iterations,
+// the convergence tests and getFitnessScore (final_transformation_ * original input) are unchanged.  The reference's
+// authors prepared this start (icp.cpp:130-134 stores the sne pose, :165-167 would move the template by it) and left
+// it commented out: opt-in here as well (cd_params.icp_use_guess).
 int icp_align(const float* src, int n, const float* tgt, int m, int nn_mode, int max_iter,
-              double trans_eps, double rel_mse, IcpOut& out) {
-    for (int i = 0; i < 16; ++i) out.T[i] = (i % 5 == 0) ? 1.f : 0.f;
+              double trans_eps, double rel_mse, IcpOut& out, const float* guess = nullptr) {
+    for (int i = 0; i < 16; ++i) out.T[i] = guess ? guess[i] : ((i % 5 == 0) ? 1.f : 0.f);
     out.iterations = 0;
     out.converged = 0;
     out.fitness = DBL_MAX;
     out.aligned.assign(src, src + 3 * (size_t)n);
     if (m <= 0) return CD_ERR_NO_TEMPLATE;
     if (n < 3) return CD_ERR_FEW_CORRESPONDENCES;  // min_number_correspondences_ = 3
+    if (guess)
+        for (int i = 0; i < n; ++i) {
+            float o[3];
+            xform(guess, src + 3 * (size_t)i, o);
+            std::memcpy(out.aligned.data() + 3 * (size_t)i, o, 12);
+        }
     KdTree kd;
     if (nn_mode == 1) kd.build(tgt, m);
     auto nn = [&](const float* q, float& d, int& j) {
@@ -1319,7 +1331,8 @@ int orc_icp(const void* tgt, size_t tstride, int m, const void* src, size_t sstr
     gather_xyz(src, sstride, n, S);
     IcpOut io;
     const int st = icp_align(S.data(), n, T.data(), m, nn_mode, prm->icp_max_iterations,
-                             prm->icp_transformation_epsilon, prm->icp_euclidean_fitness_epsilon, io);
+                             prm->icp_transformation_epsilon, prm->icp_euclidean_fitness_epsilon, io,
+                             prm->icp_use_guess != CD_GUESS_NONE ? prm->icp_guess : nullptr);
     fill_cluster_result(io, n, prm->icp_accept_fitness, out);
     if (aligned) std::memcpy(aligned, io.aligned.data(), (size_t)n * 12);
     return st;
@@ -1467,7 +1480,8 @@ int orc_process_frame_all(const void* pts, size_t stride, int n, const cd_params
         gather_xyz(tgt, tstride, m, T);
         IcpOut io;
         icp_align(src.data(), sz[k], T.data(), m, nn_mode, prm->icp_max_iterations,
-                  prm->icp_transformation_epsilon, prm->icp_euclidean_fitness_epsilon, io);
+                  prm->icp_transformation_epsilon, prm->icp_euclidean_fitness_epsilon, io,
+                  prm->icp_use_guess != CD_GUESS_NONE ? prm->icp_guess : nullptr);   // one frame per call: its guess is in prm
         cd_cluster_result cr;
         fill_cluster_result(io, sz[k], prm->icp_accept_fitness, &cr);
         if (k < CD_MAX_CLUSTERS_PER_FRAME) res->clusters[k] = cr;

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-CD_ABI_VERSION = 2
+CD_ABI_VERSION = 3
 CD_MAX_TEMPLATES = 8
 CD_MAX_CLUSTERS_PER_FRAME = 8
 CD_FRAME_MORE_CLUSTERS = 1
@@ -30,8 +30,11 @@ EXPORTED_SYMBOLS = [
     "cd_default_params", "cd_abi_version", "cd_struct_size", "cd_create", "cd_destroy", "cd_last_error",
     "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_extract", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_frame", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
-    "cd_bbox_corners", "cd_get_timing",
+    "cd_bbox_corners", "cd_get_timing", "cd_get_frame_cloud", "cd_get_cluster_points", "cd_ground_plane", "cd_set_frame_guesses",
 ]
+
+CD_CLOUD_VOXELS, CD_CLOUD_OBJECTS = 0, 1
+CD_GUESS_NONE, CD_GUESS_PARAMS, CD_GUESS_PER_FRAME = 0, 1, 2
 
 
 CD_PLANE, CD_PLANE_PERPENDICULAR, CD_PLANE_PARALLEL = 0, 1, 2
@@ -61,6 +64,7 @@ class CdParams(C.Structure):
         ("icp_accept_fitness", C.c_double),
         ("bbox_P", C.c_double * 12), ("bbox_enable", C.c_int32), ("bbox_rect", C.c_int32 * 4),
         ("plane_model", C.c_int32), ("plane_axis", C.c_float * 3), ("plane_eps_angle", C.c_double),
+        ("icp_use_guess", C.c_int32), ("icp_guess", C.c_float * 16),
     ]
 
 
@@ -168,6 +172,10 @@ def load_library(path=None):
     lib.cd_bbox_corners.argtypes = [C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double, f32p]
     lib.cd_bbox_corners.restype = None
     lib.cd_get_timing.argtypes = [vp, C.POINTER(CdTiming)]
+    lib.cd_get_frame_cloud.argtypes = [vp, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, C.c_int, ip]
+    lib.cd_get_cluster_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, ip]
+    lib.cd_ground_plane.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), f32p, vp, C.c_int, ip, ip]
+    lib.cd_set_frame_guesses.argtypes = [vp, f32p, C.c_int]
     if path is None:
         _lib = lib
     return lib
@@ -328,6 +336,50 @@ class Context:
         got = self.lib.cd_get_cluster_results(self.h, frame, first, n, out, None)
         self._check(min(0, got))
         return [out[i] for i in range(got)]
+
+    def frame_cloud(self, frame, which, stride_bytes=16, rgb_offset=12):
+        """Voxel cloud (CD_CLOUD_VOXELS) or object cloud (CD_CLOUD_OBJECTS) of `frame` of the last process_batch* call, as
+        (n, stride_bytes / 4) uint32 records: x,y,z at words 0..2, packed rgb at rgb_offset (-1: none), the rest zero."""
+        n = C.c_int()
+        st = self.lib.cd_get_frame_cloud(self.h, frame, which, None, stride_bytes, rgb_offset, 0, C.byref(n))
+        if st not in (CD_OK, CD_ERR_CAPACITY):
+            self._check(st)
+        out = np.zeros((max(n.value, 1), stride_bytes // 4), np.uint32)
+        self._check(self.lib.cd_get_frame_cloud(self.h, frame, which, _ptr(out), stride_bytes, rgb_offset, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def cluster_points(self, frame, k, aligned=False, stride_bytes=16):
+        """Points of cluster k of `frame` of the last process_batch* call (aligned: the cloud icp.align returned), as
+        (n, stride_bytes / 4) float32 records (fourth word 1.0f: pcl::PointXYZ's wire layout)."""
+        n = C.c_int()
+        st = self.lib.cd_get_cluster_points(self.h, frame, k, 1 if aligned else 0, None, stride_bytes, 0, C.byref(n))
+        if st not in (CD_OK, CD_ERR_CAPACITY):
+            self._check(st)
+        out = np.zeros((max(n.value, 1), stride_bytes // 4), np.float32)
+        self._check(self.lib.cd_get_cluster_points(self.h, frame, k, 1 if aligned else 0, _ptr(out), stride_bytes, n.value, C.byref(n)))
+        return out[:n.value]
+
+    def ground_plane(self, points, prm):
+        """gps.cpp:43-112 as one call.  points: (n, k) float32 records.  Returns (status, coeff, kept records (m, k) uint32 view
+        of the input's layout, n_inliers)."""
+        a = np.ascontiguousarray(points, dtype=np.float32)
+        assert a.ndim == 2 and a.shape[1] >= 3
+        n, stride = a.shape[0], a.shape[1] * 4
+        coeff = np.zeros(4, np.float32)
+        out = np.zeros((max(n, 1), a.shape[1]), np.uint32)
+        m, ni = C.c_int(), C.c_int()
+        st = self.lib.cd_ground_plane(self.h, _ptr(a), stride, n, C.byref(prm), coeff.ctypes.data_as(C.POINTER(C.c_float)), _ptr(out), n,
+                                      C.byref(m), C.byref(ni))
+        self._check(st, ok=(CD_OK, CD_ERR_NO_MODEL))
+        return st, coeff, out[:m.value].copy(), ni.value
+
+    def set_frame_guesses(self, guesses):
+        """Per-frame initial guesses (F, 4, 4) float32 for prm.icp_use_guess = CD_GUESS_PER_FRAME; None clears."""
+        if guesses is None:
+            self._check(self.lib.cd_set_frame_guesses(self.h, None, 0))
+            return
+        g = np.ascontiguousarray(guesses, np.float32).reshape(-1, 16)
+        self._check(self.lib.cd_set_frame_guesses(self.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.shape[0]))
 
     def timing(self):
         t = CdTiming()

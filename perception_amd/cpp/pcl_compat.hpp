@@ -220,6 +220,13 @@ public:
     void setTransformationEpsilon(double e) { prm_.icp_transformation_epsilon = e; }
     void setEuclideanFitnessEpsilon(double e) { prm_.icp_euclidean_fitness_epsilon = e; }
     void setRANSACOutlierRejectionThreshold(double) {}   // inert in PCL too: no rejector is installed (icp.cpp:177)
+    // align(output, guess): pcl::Registration's second overload (row-major 4x4, scene -> template)
+    void align(PointCloud<PointSource>& output, const Matrix4& guess) {
+        prm_.icp_use_guess = CD_GUESS_PARAMS;
+        std::memcpy(prm_.icp_guess, guess.data(), 64);
+        align(output);
+        prm_.icp_use_guess = CD_GUESS_NONE;
+    }
     void align(PointCloud<PointSource>& output) {
         output.clear();
         converged_ = false;
@@ -257,60 +264,145 @@ private:
     double fitness_ = 0;
 };
 
-// pcl::io::loadPCDFile<PointXYZ> for ASCII/binary PCD v0.7 with float x y z fields (icp.cpp:159)
+// pcl::io::loadPCDFile<PointXYZ> (icp.cpp:159, opd.cpp:398): PCD v0.7 (and v0.6's COLUMNS alias) in all three DATA
+// encodings.  The header's FIELDS / SIZE / TYPE / COUNT lines give the record layout - a field of COUNT c occupies
+// c * SIZE bytes (binary) or c tokens (ascii) -, WIDTH x HEIGHT stands in for a missing POINTS line, x / y / z are picked by
+// name and converted to float32 from whatever TYPE / SIZE they are stored as (PCL maps F4 directly; F8 and the integer
+// types are cast here rather than dropped).  binary_compressed = two uint32 (compressed, uncompressed size) + an LZF stream
+// of the fields stored one after the other (all x, then all y, ...), as pcl::PCDWriter::writeBinaryCompressed lays it out.
+// Returns 0, or -1 with a message on stderr (PCL_ERROR at the call sites follows).
 namespace io {
-inline int loadPCDFile(const std::string& path, PointCloud<PointXYZ>& cloud) {
-    cloud.clear();
-    FILE* f = std::fopen(path.c_str(), "rb");
-    if (!f) return -1;
-    char line[512];
-    std::vector<std::string> fields;
-    std::vector<int> sizes;
-    long npts = -1;
-    bool binary = false, have_data = false;
-    while (std::fgets(line, sizeof(line), f)) {
-        std::string s(line);
-        if (s.rfind("FIELDS", 0) == 0 || s.rfind("SIZE", 0) == 0) {
-            const bool is_f = s[0] == 'F';
-            size_t p = s.find(' ');
-            while (p != std::string::npos) {
-                const size_t q = s.find_first_of(" \r\n", p + 1);
-                const std::string tok = s.substr(p + 1, q == std::string::npos ? q : q - p - 1);
-                if (!tok.empty()) { if (is_f) fields.push_back(tok); else sizes.push_back(std::atoi(tok.c_str())); }
-                p = (q == std::string::npos || s[q] != ' ') ? std::string::npos : q;
-            }
-        } else if (s.rfind("POINTS", 0) == 0) {
-            npts = std::atol(s.c_str() + 7);
-        } else if (s.rfind("DATA", 0) == 0) {
-            binary = s.find("binary") != std::string::npos;
-            have_data = true;
-            break;
+namespace detail {
+// liblzf's decompressor (format: literal runs `000LLLLL` + L+1 bytes; back references `LLLooooo oooooooo`, LLL = 7 adds a
+// length byte): returns the number of bytes produced, 0 on a malformed stream
+inline size_t lzf_decompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len) {
+    const unsigned char* ip = in;
+    const unsigned char* const in_end = in + in_len;
+    unsigned char* op = out;
+    unsigned char* const out_end = out + out_len;
+    while (ip < in_end) {
+        unsigned ctrl = *ip++;
+        if (ctrl < 32) {
+            ++ctrl;
+            if (op + ctrl > out_end || ip + ctrl > in_end) return 0;
+            std::memcpy(op, ip, ctrl);
+            op += ctrl; ip += ctrl;
+        } else {
+            unsigned len = ctrl >> 5;
+            if (ip >= in_end) return 0;
+            if (len == 7) { len += *ip++; if (ip >= in_end) return 0; }
+            const size_t dist = ((size_t)(ctrl & 0x1f) << 8) + (size_t)*ip++ + 1;
+            len += 2;
+            if (op + len > out_end || dist > (size_t)(op - out)) return 0;
+            const unsigned char* ref = op - dist;
+            for (unsigned k = 0; k < len; ++k) *op++ = *ref++;   // may overlap: byte by byte
         }
     }
+    return (size_t)(op - out);
+}
+struct PcdField { std::string name; int size = 4; char type = 'F'; int count = 1; size_t offset = 0; };
+inline float pcd_value(const unsigned char* p, const PcdField& f) {
+    if (f.type == 'F') { if (f.size == 4) { float v; std::memcpy(&v, p, 4); return v; } if (f.size == 8) { double v; std::memcpy(&v, p, 8); return (float)v; } }
+    if (f.type == 'I') { if (f.size == 1) { int8_t v; std::memcpy(&v, p, 1); return (float)v; } if (f.size == 2) { int16_t v; std::memcpy(&v, p, 2); return (float)v; }
+                         if (f.size == 4) { int32_t v; std::memcpy(&v, p, 4); return (float)v; } if (f.size == 8) { int64_t v; std::memcpy(&v, p, 8); return (float)v; } }
+    if (f.type == 'U') { if (f.size == 1) { uint8_t v; std::memcpy(&v, p, 1); return (float)v; } if (f.size == 2) { uint16_t v; std::memcpy(&v, p, 2); return (float)v; }
+                         if (f.size == 4) { uint32_t v; std::memcpy(&v, p, 4); return (float)v; } if (f.size == 8) { uint64_t v; std::memcpy(&v, p, 8); return (float)v; } }
+    return std::numeric_limits<float>::quiet_NaN();
+}
+inline std::vector<std::string> pcd_tokens(const std::string& line) {
+    std::vector<std::string> t;
+    size_t i = 0;
+    while (i < line.size()) {
+        while (i < line.size() && std::strchr(" \t\r\n", line[i])) ++i;
+        size_t j = i;
+        while (j < line.size() && !std::strchr(" \t\r\n", line[j])) ++j;
+        if (j > i) t.push_back(line.substr(i, j - i));
+        i = j;
+    }
+    return t;
+}
+}  // namespace detail
+
+inline int loadPCDFile(const std::string& path, PointCloud<PointXYZ>& cloud) {
+    using namespace detail;
+    cloud.clear();
+    auto err = [&](const char* what) { std::fprintf(stderr, "[pclhip::io::loadPCDFile] %s: %s\n", path.c_str(), what); return -1; };
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return err("cannot open the file");
+    struct Closer { FILE* f; ~Closer() { std::fclose(f); } } closer{f};
+    std::vector<PcdField> fields;
+    long npts = -1, width = -1, height = -1;
+    std::string data;
+    char line[4096];
+    while (std::fgets(line, sizeof(line), f)) {
+        const std::vector<std::string> t = pcd_tokens(line);
+        if (t.empty() || t[0][0] == '#') continue;
+        const std::string& key = t[0];
+        if (key == "FIELDS" || key == "COLUMNS") {
+            fields.assign(t.size() - 1, PcdField());
+            for (size_t k = 1; k < t.size(); ++k) fields[k - 1].name = t[k];
+        } else if (key == "SIZE" || key == "TYPE" || key == "COUNT") {
+            if (t.size() - 1 != fields.size()) return err("SIZE / TYPE / COUNT does not match FIELDS");
+            for (size_t k = 1; k < t.size(); ++k) {
+                if (key == "SIZE") fields[k - 1].size = std::atoi(t[k].c_str());
+                else if (key == "TYPE") fields[k - 1].type = t[k][0];
+                else fields[k - 1].count = std::atoi(t[k].c_str());
+            }
+        } else if (key == "WIDTH" && t.size() > 1) { width = std::atol(t[1].c_str());
+        } else if (key == "HEIGHT" && t.size() > 1) { height = std::atol(t[1].c_str());
+        } else if (key == "POINTS" && t.size() > 1) { npts = std::atol(t[1].c_str());
+        } else if (key == "DATA" && t.size() > 1) { data = t[1]; break; }
+    }
+    if (data.empty()) return err("no DATA line");
+    if (npts < 0 && width >= 0) npts = width * (height >= 0 ? height : 1);     // POINTS is optional: WIDTH x HEIGHT
+    if (npts < 0) return err("neither POINTS nor WIDTH / HEIGHT");
     int ix = -1, iy = -1, iz = -1;
-    for (size_t i = 0; i < fields.size(); ++i) { if (fields[i] == "x") ix = (int)i; if (fields[i] == "y") iy = (int)i; if (fields[i] == "z") iz = (int)i; }
-    if (!have_data || npts < 0 || ix < 0 || iy < 0 || iz < 0) { std::fclose(f); return -1; }
+    size_t step = 0, tokens = 0;
+    for (size_t k = 0; k < fields.size(); ++k) {
+        PcdField& fd = fields[k];
+        if (fd.size <= 0 || fd.count < 0 || !std::strchr("FIU", fd.type)) return err("bad SIZE / TYPE / COUNT entry");
+        fd.offset = step;
+        step += (size_t)fd.size * (size_t)fd.count;
+        tokens += (size_t)fd.count;
+        if (fd.count >= 1) { if (fd.name == "x") ix = (int)k; if (fd.name == "y") iy = (int)k; if (fd.name == "z") iz = (int)k; }
+    }
+    if (ix < 0 || iy < 0 || iz < 0) return err("no x / y / z fields");
     cloud.points.resize((size_t)npts);
-    if (!binary) {
-        std::vector<double> row(fields.size());
+    if (data == "ascii") {
+        // token positions of x, y, z within a row (a field of COUNT c contributes c tokens)
+        size_t tx = 0, ty = 0, tz = 0, acc = 0;
+        for (size_t k = 0; k < fields.size(); ++k) { if ((int)k == ix) tx = acc; if ((int)k == iy) ty = acc; if ((int)k == iz) tz = acc; acc += (size_t)fields[k].count; }
+        std::vector<double> row(tokens);
+        char tok[128];
         for (long i = 0; i < npts; ++i) {
-            for (size_t k = 0; k < fields.size(); ++k) if (std::fscanf(f, "%lf", &row[k]) != 1) { std::fclose(f); return -1; }
-            cloud.points[(size_t)i] = PointXYZ((float)row[(size_t)ix], (float)row[(size_t)iy], (float)row[(size_t)iz]);
+            for (size_t k = 0; k < tokens; ++k) {
+                if (std::fscanf(f, "%127s", tok) != 1) return err("ascii data ends early");
+                row[k] = std::strtod(tok, nullptr);                           // handles nan / inf
+            }
+            cloud.points[(size_t)i] = PointXYZ((float)row[tx], (float)row[ty], (float)row[tz]);
         }
-    } else {
-        size_t step = 0;
-        std::vector<size_t> off(fields.size());
-        for (size_t k = 0; k < fields.size(); ++k) { off[k] = step; step += (size_t)(k < sizes.size() ? sizes[k] : 4); }
+    } else if (data == "binary") {
         std::vector<unsigned char> rec(step);
         for (long i = 0; i < npts; ++i) {
-            if (std::fread(rec.data(), 1, step, f) != step) { std::fclose(f); return -1; }
-            PointXYZ p;
-            std::memcpy(&p.x, &rec[off[(size_t)ix]], 4); std::memcpy(&p.y, &rec[off[(size_t)iy]], 4); std::memcpy(&p.z, &rec[off[(size_t)iz]], 4);
-            cloud.points[(size_t)i] = p;
+            if (std::fread(rec.data(), 1, step, f) != step) return err("binary data ends early");
+            cloud.points[(size_t)i] = PointXYZ(pcd_value(&rec[fields[(size_t)ix].offset], fields[(size_t)ix]), pcd_value(&rec[fields[(size_t)iy].offset], fields[(size_t)iy]),
+                                               pcd_value(&rec[fields[(size_t)iz].offset], fields[(size_t)iz]));
         }
+    } else if (data == "binary_compressed") {
+        uint32_t sz[2];
+        if (std::fread(sz, 4, 2, f) != 2) return err("binary_compressed: no size words");
+        if ((size_t)sz[1] != step * (size_t)npts) return err("binary_compressed: uncompressed size does not match the header");
+        std::vector<unsigned char> in(sz[0]), out(sz[1]);
+        if (sz[0] && std::fread(in.data(), 1, sz[0], f) != sz[0]) return err("binary_compressed data ends early");
+        if (sz[1] && lzf_decompress(in.data(), in.size(), out.data(), out.size()) != out.size()) return err("binary_compressed: malformed LZF stream");
+        // fields one after the other: field k occupies npts * size * count bytes starting at npts * offset_k
+        auto at = [&](int k, long i) { const PcdField& fd = fields[(size_t)k]; return pcd_value(&out[fd.offset * (size_t)npts + (size_t)i * (size_t)fd.size * (size_t)fd.count], fd); };
+        for (long i = 0; i < npts; ++i) cloud.points[(size_t)i] = PointXYZ(at(ix, i), at(iy, i), at(iz, i));
+    } else {
+        return err("unknown DATA encoding");
     }
-    cloud.width = (uint32_t)npts;
-    std::fclose(f);
+    cloud.width = width >= 0 && height > 1 ? (uint32_t)width : (uint32_t)npts;
+    cloud.height = width >= 0 && height > 1 ? (uint32_t)height : 1;
     return 0;
 }
 }  // namespace io

@@ -38,28 +38,12 @@ void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
     prm.crop2_enable = 0;
     prm.rgb_offset = field_offset(*input, "rgb");
     const int n = (int)(input->width * input->height);
-    std::vector<float> vox((size_t)n * 3);
-    std::vector<uint32_t> rgb((size_t)n);
-    int nc = 0, nv = 0;
-    if (cd_crop_voxel(ctx, input->data.data(), input->point_step, n, &prm, vox.data(), rgb.data(), n, &nc, &nv) != CD_OK) return;
-    std::vector<pclhip::PointXYZ> pts((size_t)nv);
-    for (int i = 0; i < nv; ++i) pts[(size_t)i] = pclhip::PointXYZ(vox[3 * i], vox[3 * i + 1], vox[3 * i + 2]);
-    std::vector<int32_t> inl((size_t)std::max(nv, 1));
-    float coeff[4] = {0, 0, 0, 0};
-    int ni = 0, it = 0;
-    const int st = cd_segment_plane(ctx, pts.data(), sizeof(pclhip::PointXYZ), nv, &prm, coeff, inl.data(), nv, &ni, &it);
-    pcl_msgs::ModelCoefficients ros_coefficients;
-    ros_coefficients.header = input->header;
-    if (st == CD_OK) ros_coefficients.values.assign(coeff, coeff + 4);
-    coef_pub.publish(ros_coefficients);
-    // ExtractIndices<PCLPointCloud2>(negative = invert) + fromPCL (gps.cpp:96-112): the published cloud carries the INPUT's
-    // field table and point_step - VoxelGrid<PCLPointCloud2> and ExtractIndices<PCLPointCloud2> both copy them - with one
-    // record per kept voxel: centroid at the x,y,z offsets, averaged colour at the rgb offset, padding bytes zero.
+    // ONE library call for the callback's body (gps.cpp:53-101): one upload of the blob, one download of the records to
+    // publish.  ExtractIndices<PCLPointCloud2>(negative = invert) + fromPCL (gps.cpp:96-112): the published cloud carries the
+    // INPUT's field table and point_step - VoxelGrid<PCLPointCloud2> and ExtractIndices<PCLPointCloud2> both copy them - with
+    // one record per kept voxel: centroid at the x,y,z offsets, averaged colour at the rgb offset, padding bytes zero.
     // (PCL also averages any OTHER field as a float32; the D435 driver publishes none, and here they stay zero.)
-    std::vector<char> is_inl((size_t)std::max(nv, 1), 0);
-    for (int k = 0; k < ni; ++k) is_inl[(size_t)inl[(size_t)k]] = 1;
-    const int ox = field_offset(*input, "x"), oy = field_offset(*input, "y"), oz = field_offset(*input, "z");
-    const int orgb = prm.rgb_offset >= 0 ? prm.rgb_offset : field_offset(*input, "rgba");
+    if (prm.rgb_offset < 0) prm.rgb_offset = field_offset(*input, "rgba");
     sensor_msgs::PointCloud2 out;
     out.header = input->header;
     out.height = 1;
@@ -67,19 +51,16 @@ void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
     out.is_bigendian = input->is_bigendian;
     out.fields = input->fields;
     out.point_step = input->point_step;
-    size_t kept = 0;
-    for (int i = 0; i < nv; ++i) kept += ((is_inl[(size_t)i] != 0) == invert) ? 0 : 1;
-    out.data.assign(kept * out.point_step, 0);
-    size_t o = 0;
-    for (int i = 0; i < nv; ++i) {
-        if ((is_inl[(size_t)i] != 0) == invert) continue;
-        uint8_t* rec = &out.data[o];
-        std::memcpy(rec + ox, &vox[3 * (size_t)i], 4);
-        std::memcpy(rec + oy, &vox[3 * (size_t)i + 1], 4);
-        std::memcpy(rec + oz, &vox[3 * (size_t)i + 2], 4);
-        if (orgb >= 0 && (size_t)orgb + 4 <= out.point_step) std::memcpy(rec + orgb, &rgb[(size_t)i], 4);
-        o += out.point_step;
-    }
+    out.data.assign((size_t)n * out.point_step, 0);
+    float coeff[4] = {0, 0, 0, 0};
+    int kept = 0, ni = 0;
+    const int st = cd_ground_plane(ctx, input->data.data(), input->point_step, n, &prm, coeff, out.data.data(), n, &kept, &ni);
+    if (st != CD_OK && st != CD_ERR_NO_MODEL) { ROS_ERROR("%s", cd_last_error(ctx)); return; }
+    pcl_msgs::ModelCoefficients ros_coefficients;
+    ros_coefficients.header = input->header;
+    if (st == CD_OK) ros_coefficients.values.assign(coeff, coeff + 4);      // PCL leaves them empty when no plane was found
+    coef_pub.publish(ros_coefficients);
+    out.data.resize((size_t)kept * out.point_step);
     out.width = (uint32_t)kept;
     out.row_step = out.width * out.point_step;
     pcl_pub.publish(out);

@@ -81,6 +81,14 @@ struct cd_context {
     size_t koffx_cap = 0;
     std::vector<cd_cluster_result> last_clusters;                 // every cluster result of the last batch, frame-major
     std::vector<int> last_first;                                  // index of frame f's first cluster in it (F + 1 entries)
+    // clouds of the last batch that stay resident for cd_get_frame_cloud / cd_get_cluster_points
+    std::vector<int> last_nv, last_no;                            // voxels / object points per frame
+    std::vector<long long> last_orig_off, last_al_off;            // per cluster: offset of its points in d_src0; of its aligned points in d_src (-1: not resident)
+    bool last_clouds = false;
+    // initial guesses (cd_set_frame_guesses), and their device copy (also used for the single guess of cd_params)
+    std::vector<float> frame_guess;
+    float* d_guess = nullptr;
+    size_t guess_cap = 0;
     IcpState *d_st = nullptr, *h_st = nullptr;
     unsigned long long *d_acc = nullptr, *d_accf = nullptr, *h_accf = nullptr;
     hipEvent_t ev[8] = {nullptr};
@@ -111,6 +119,13 @@ namespace {
         }                                                                                                     \
     } while (0)
 
+// the per-batch read-backs (cd_get_cluster_results, cd_get_frame_cloud, cd_get_cluster_points) describe the last fused call;
+// every other compute call reuses the same device buffers
+void invalidate_last(cd_context* c) {
+    c->last_clouds = false;
+    c->last_first.clear();
+}
+
 int fail(cd_context* c, int code, const char* msg) {
     snprintf(c->err, sizeof(c->err), "%s", msg);
     return code;
@@ -123,6 +138,13 @@ hipError_t halloc(Tp** p, size_t n) { return hipHostMalloc((void**)p, std::max<s
 
 const int FS_PITCH = (int)(sizeof(FrameState) / sizeof(int));
 #define FS_FIELD(ctx, field) ((int*)((char*)(ctx)->d_fs + offsetof(FrameState, field)))
+
+// blocking copy ordered on the context's own (non-blocking) stream: the NULL stream gives no ordering against it
+static hipError_t copy_sync(cd_context* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(c->stream);
+}
 
 int ensure_input(cd_context* c, size_t bytes) {
     if (bytes <= c->d_in_bytes) return CD_OK;
@@ -409,6 +431,26 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     c->timing.icp_kernel_ms = 0.f;
     if (pair_tests) *pair_tests = 0;
     if (ncl <= 0) return CD_OK;
+    // initial guess (pcl::Registration::align(output, guess)); the default - and the reference's live path - is none
+    const int guess_mode = p->icp_use_guess;
+    int max_n = 0;
+    if (guess_mode != CD_GUESS_NONE) {
+        int max_frame = 0;
+        for (int k = 0; k < ncl; ++k) { max_n = std::max(max_n, c->h_cl[k].n); max_frame = std::max(max_frame, c->h_cl[k].frame); }
+        const size_t need = guess_mode == CD_GUESS_PER_FRAME ? 16 * ((size_t)max_frame + 1) : 16;
+        if (guess_mode == CD_GUESS_PER_FRAME && c->frame_guess.size() < need) return fail(c, CD_ERR_INVALID_ARG, "icp_use_guess = CD_GUESS_PER_FRAME but cd_set_frame_guesses holds fewer frames than the batch");
+        if (need > c->guess_cap) {
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            if (c->d_guess) hipFree(c->d_guess);
+            c->d_guess = nullptr; c->guess_cap = 0;
+            HIPCHK(c, dalloc(&c->d_guess, need));
+            c->guess_cap = need;
+        }
+        HIPCHK(c, copy_sync(c, c->d_guess, guess_mode == CD_GUESS_PER_FRAME ? c->frame_guess.data() : p->icp_guess, sizeof(float) * need, hipMemcpyHostToDevice));
+    }
+    auto guess_of = [&](const IcpCluster& cl) -> const float* {
+        return guess_mode == CD_GUESS_PER_FRAME ? c->frame_guess.data() + 16 * (size_t)cl.frame : p->icp_guess;
+    };
     // queries per workgroup: 512 when the batch fills the chip, smaller slices (more workgroups) otherwise
     long long qtot = 0;
     for (int k = 0; k < ncl; ++k) qtot += c->h_cl[k].n;
@@ -451,6 +493,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             IcpState& st = c->h_st[2 * k + s];
             std::memset(&st, 0, sizeof(st));
             for (int i = 0; i < 4; ++i) st.Tfinal[5 * i] = 1.f;
+            if (guess_mode != CD_GUESS_NONE) std::memcpy(st.Tfinal, guess_of(cl), 64);   // final_transformation_ = guess
             st.prev_mse = std::numeric_limits<double>::max();
             if (cl.tpl_m <= 0) { st.done = 1; st.status = CD_ERR_NO_TEMPLATE; }
             else if (cl.n < 3) { st.done = 1; st.status = CD_ERR_FEW_CORRESPONDENCES; }
@@ -461,6 +504,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
+    if (guess_mode != CD_GUESS_NONE)   // input_transformed = guess * source (d_src is a copy of d_src0 at this point)
+        LAUNCH(c, launch_icp_apply_guess(c->stream, ncl, max_n, c->d_cl, c->d_guess, guess_mode == CD_GUESS_PER_FRAME ? 1 : 0, c->d_src0, c->d_src));
     IcpParams ip;
     ip.max_iter = p->icp_max_iterations;
     ip.grid_rc = 1.0f;
@@ -606,6 +651,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             long long span = 0;
             for (int k = 0; k < ncl; ++k) span = std::max(span, (long long)c->h_cl[k].src_off + c->h_cl[k].n);
             HIPCHK(c, hipMemcpyAsync(c->d_src, c->d_src0, sizeof(float4) * (size_t)span, hipMemcpyDeviceToDevice, c->stream));
+            if (guess_mode != CD_GUESS_NONE)
+                LAUNCH(c, launch_icp_apply_guess(c->stream, ncl, max_n, c->d_cl, c->d_guess, guess_mode == CD_GUESS_PER_FRAME ? 1 : 0, c->d_src0, c->d_src));
         }
     }
     // The iteration kernel walks an ACTIVE work list (d_work2) that the host re-packs at every
@@ -669,13 +716,6 @@ void fill_cluster_result(const cd_context* c, int k, const cd_params* p, cd_clus
         for (int i = 0; i < 16; ++i) r->pose[i] = std::numeric_limits<double>::quiet_NaN();
 }
 
-// blocking copy ordered on the context's own (non-blocking) stream: the NULL stream gives no ordering against it
-static hipError_t copy_sync(cd_context* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, c->stream);
-    if (e != hipSuccess) return e;
-    return hipStreamSynchronize(c->stream);
-}
-
 int upload_points(cd_context* c, const void* pts, size_t stride, int n, float4* dst) {
     // host (stride) -> device float4 via the staging buffer
     if (n <= 0) return CD_OK;
@@ -698,6 +738,9 @@ int check_params(cd_context* c, const cd_params* p) {
     if (p->template_slot < -1 || p->template_slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "template_slot out of range");
     if (!(p->cluster_tolerance > 0.0)) return fail(c, CD_ERR_INVALID_ARG, "cluster_tolerance must be > 0");
     if (p->plane_model < CD_PLANE || p->plane_model > CD_PLANE_PARALLEL) return fail(c, CD_ERR_INVALID_ARG, "plane_model out of range");
+    if (p->icp_use_guess < CD_GUESS_NONE || p->icp_use_guess > CD_GUESS_PER_FRAME) return fail(c, CD_ERR_INVALID_ARG, "icp_use_guess out of range");
+    if (p->icp_use_guess == CD_GUESS_PARAMS)
+        for (int i = 0; i < 16; ++i) if (!std::isfinite(p->icp_guess[i])) return fail(c, CD_ERR_INVALID_ARG, "icp_guess holds a non-finite value");
     return CD_OK;
 }
 
@@ -708,6 +751,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     if (!results || !d_frames) return fail(c, CD_ERR_INVALID_ARG, "null pointer");
     if (N <= 0 || F <= 0 || stride < 12 || (stride & 3)) return fail(c, CD_ERR_INVALID_ARG, "bad shape/stride");
     if (N > c->N || F > c->F) return fail(c, CD_ERR_CAPACITY, "batch larger than the context capacity");
+    invalidate_last(c);
     std::memset(&c->timing, 0, sizeof(c->timing));
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int rounds = 0;
@@ -801,6 +845,12 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     c->last_first.clear();
     std::vector<cd_cluster_result>& best = c->last_clusters;
     best.assign((size_t)std::max(ncl, 1), cd_cluster_result());
+    std::vector<long long> orig_off((size_t)std::max(ncl, 1), -1), al_off((size_t)std::max(ncl, 1), -1);   // see cd_get_cluster_points
+    {
+        int q = 0;
+        for (int f = 0; f < F; ++f)
+            for (int k = 0; k < c->h_fs[f].n_k; ++k, ++q) orig_off[(size_t)q] = (long long)f * c->N + coff[(size_t)q];
+    }
     long long pairs = 0;
     // Several templates: when S copies of every frame's ICP sources fit its segment of the source buffers (they do unless a
     // frame is nearly all objects), every (cluster, template) pair becomes one ICP problem of ONE stage - the batch then
@@ -865,7 +915,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
                 cd_cluster_result r;
                 fill_cluster_result(c, t * ncl + k, p, &r);
                 r.template_slot = slots[(size_t)t];
-                if (t == 0 || r.fitness < best[(size_t)k].fitness) best[(size_t)k] = r;
+                if (t == 0 || r.fitness < best[(size_t)k].fitness) { best[(size_t)k] = r; al_off[(size_t)k] = c->h_cl[(size_t)t * ncl + k].src_off; }
             }
     }
     for (size_t si = 0; si < slots.size() && !one_stage; ++si) {
@@ -894,10 +944,16 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
             cd_cluster_result r;
             fill_cluster_result(c, k, p, &r);
             r.template_slot = slot;
-            if (si == 0 || r.fitness < best[(size_t)k].fitness) best[(size_t)k] = r;
+            // (the aligned cloud of a pass stays in d_src only until the next pass re-extracts the sources)
+            if (si == 0 || r.fitness < best[(size_t)k].fitness) { best[(size_t)k] = r; al_off[(size_t)k] = si + 1 == slots.size() ? (long long)c->h_cl[k].src_off : -1; }
         }
     }
     c->last_first = first_cl;
+    c->last_orig_off.swap(orig_off);
+    c->last_al_off.swap(al_off);
+    c->last_nv.resize((size_t)F); c->last_no.resize((size_t)F);
+    for (int f = 0; f < F; ++f) { c->last_nv[(size_t)f] = c->h_fs[f].n_v; c->last_no[(size_t)f] = c->h_fs[f].n_o; }
+    c->last_clouds = true;
     HIPCHK(c, hipEventRecord(c->ev[4], c->stream));
     // records
     long long balg = 0;
@@ -1003,6 +1059,7 @@ void cd_destroy(cd_context* c) {
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     if (c->d_koffx) hipFree(c->d_koffx);
+    if (c->d_guess) hipFree(c->d_guess);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf, c->h_wgtab, c->h_ctl};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -1353,6 +1410,7 @@ int cd_crop_voxel(cd_context* c, const void* points, size_t stride, int n, const
                   uint32_t* out_rgb, int capacity, int* out_n_cropped, int* out_n_voxels) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     int st = check_params(c, p);
     if (st) return st;
     if (!points || !out_xyz || n < 0 || stride < 12 || (stride & 3)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1405,6 +1463,7 @@ int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const
                      int32_t* inliers, int capacity, int* out_n_inliers, int* out_iterations) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     int st = check_params(c, p);
     if (st) return st;
     if (!xyz || !coeff || !inliers || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1439,6 +1498,7 @@ int cd_surface_frame(cd_context* c, const void* xyz, size_t stride, int n, const
                      const cd_params* p, cd_surface_frame_result* out) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     int st = check_params(c, p);
     if (st) return st;
     if ((!xyz && n > 0) || !table_normal || !out || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1511,6 +1571,7 @@ int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const d
                    int32_t* out_indices, int capacity, int* out_n) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     if ((!xyz && n > 0) || !P || !rect || !out_indices || !out_n || n < 0 || stride < 12) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
     *out_n = 0;
     if (n == 0) return CD_OK;
@@ -1536,6 +1597,7 @@ int cd_extract(cd_context* c, const void* points, size_t stride, int n, const in
                void* out_points, int capacity, int* out_n) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     if ((!points && n > 0) || (!indices && n_indices > 0) || !out_n || n < 0 || n_indices < 0 || capacity < 0 || stride < 4 || (stride & 3) ||
         (!out_points && capacity > 0))
         return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1586,6 +1648,7 @@ int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_pa
                int32_t* sizes, int sizes_capacity, int* out_k) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     int st = check_params(c, p);
     if (st) return st;
     if (!xyz || !labels || n < 0 || stride < 12 || (sizes_capacity > 0 && !sizes)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1607,6 +1670,7 @@ int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, c
            cd_cluster_result* out, float* aligned) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
+    invalidate_last(c);
     int st = check_params(c, p);
     if (st) return st;
     if (!src_xyz || !out || n < 0 || stride < 12 || slot < 0 || slot >= CD_MAX_TEMPLATES) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
@@ -1664,6 +1728,127 @@ int cd_get_cluster_results(const cd_context* c, int frame, int first, int capaci
     int n = 0;
     for (int k = lo + first; k < hi && n < capacity; ++k) out[n++] = c->last_clusters[(size_t)k];
     return n;
+}
+
+// float4 points on the device -> `m` records of `stride` bytes in caller memory (k_pack_records, then ONE download).
+// The staging area is the context's input buffer (its contents - the frames of a host-pointer call - are dead by now).
+static int download_records(cd_context* c, const float4* d_pts, int m, size_t stride, int rgb_offset, uint32_t pad3, void* out,
+                            size_t staging_skip = 0) {
+    if (m <= 0) return CD_OK;
+    const size_t skip = (staging_skip + 255) & ~(size_t)255;
+    int st = CD_OK;
+    if (skip + (size_t)m * stride > c->d_in_bytes) {
+        if (skip) return fail(c, CD_ERR_CAPACITY, "record staging area too small");   // (callers that keep the input size the buffer beforehand)
+        st = ensure_input(c, (size_t)m * stride);
+        if (st) return st;
+    }
+    char* d_out = c->d_in + skip;
+    LAUNCH(c, launch_pack_records(c->stream, d_pts, m, (int)(stride / 4), rgb_offset >= 0 ? rgb_offset / 4 : -1, pad3, d_out));
+    HIPCHK(c, copy_sync(c, out, d_out, (size_t)m * stride, hipMemcpyDeviceToHost));
+    return CD_OK;
+}
+
+int cd_get_frame_cloud(cd_context* c, int frame, int which, void* out_records, size_t stride, int rgb_offset, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if (!out_n || capacity < 0 || (capacity > 0 && !out_records) || stride < 12 || (stride & 3) || (which != CD_CLOUD_VOXELS && which != CD_CLOUD_OBJECTS) ||
+        (rgb_offset >= 0 && (rgb_offset < 12 || (rgb_offset & 3) || (size_t)rgb_offset + 4 > stride)))
+        return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (!c->last_clouds || frame < 0 || (size_t)frame >= c->last_nv.size()) return fail(c, CD_ERR_INVALID_ARG, "not a frame of the last fused call of this context");
+    const int m = which == CD_CLOUD_VOXELS ? c->last_nv[(size_t)frame] : c->last_no[(size_t)frame];
+    if (m > capacity) { *out_n = m; return fail(c, CD_ERR_CAPACITY, "output capacity too small"); }
+    const float4* src = (which == CD_CLOUD_VOXELS ? c->d_vox : c->d_obj) + (size_t)frame * c->N;
+    const int st = download_records(c, src, m, stride, rgb_offset, 0u, out_records);
+    if (st) return st;
+    *out_n = m;
+    return CD_OK;
+}
+
+int cd_get_cluster_points(cd_context* c, int frame, int k, int aligned, void* out_points, size_t stride, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    if (!out_n || capacity < 0 || (capacity > 0 && !out_points) || stride < 12 || (stride & 3)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (!c->last_clouds || frame < 0 || (size_t)frame + 1 >= c->last_first.size()) return fail(c, CD_ERR_INVALID_ARG, "not a frame of the last fused call of this context");
+    const int lo = c->last_first[(size_t)frame], hi = c->last_first[(size_t)frame + 1];
+    if (k < 0 || lo + k >= hi || (size_t)(lo + k) >= c->last_clusters.size()) return fail(c, CD_ERR_INVALID_ARG, "no such cluster");
+    const cd_cluster_result& r = c->last_clusters[(size_t)(lo + k)];
+    const int m = r.size;
+    if (m > capacity) { *out_n = m; return fail(c, CD_ERR_CAPACITY, "output capacity too small"); }
+    const long long o0 = c->last_orig_off[(size_t)(lo + k)], o1 = c->last_al_off[(size_t)(lo + k)];
+    const uint32_t one = 0x3f800000u;   // pcl::PointXYZ::data[3]
+    int st;
+    if (!aligned || o1 >= 0) {
+        st = download_records(c, (aligned ? c->d_src : c->d_src0) + (aligned ? o1 : o0), m, stride, -1, one, out_points);
+        if (st) return st;
+    } else {
+        // the pass that produced the best result has been overwritten by a later template pass: final_transformation * cluster
+        st = download_records(c, c->d_src0 + o0, m, stride, -1, one, out_points);
+        if (st) return st;
+        for (int i = 0; i < m; ++i) {
+            float v[3];
+            char* rec = (char*)out_points + (size_t)i * stride;
+            std::memcpy(v, rec, 12);
+            const float* T = r.T;
+            const float o[3] = {((T[0] * v[0] + T[1] * v[1]) + T[2] * v[2]) + T[3], ((T[4] * v[0] + T[5] * v[1]) + T[6] * v[2]) + T[7],
+                                ((T[8] * v[0] + T[9] * v[1]) + T[10] * v[2]) + T[11]};
+            std::memcpy(rec, o, 12);
+        }
+    }
+    *out_n = m;
+    return CD_OK;
+}
+
+int cd_ground_plane(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float coeff[4], void* out_records,
+                    int capacity, int* out_n, int* out_n_inliers) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    invalidate_last(c);
+    int st = check_params(c, p);
+    if (st) return st;
+    if ((!points && n > 0) || !coeff || !out_n || n < 0 || capacity < 0 || (capacity > 0 && !out_records) || stride < 12 || (stride & 3))
+        return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (out_n_inliers) *out_n_inliers = 0;
+    if (n > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    if (n == 0) return CD_ERR_NO_MODEL;
+    // one buffer: the input blob, then (256-byte aligned) room for the records that go back
+    const size_t in_bytes = (size_t)n * stride;
+    st = ensure_input(c, ((in_bytes + 255) & ~(size_t)255) + in_bytes);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, points, in_bytes, hipMemcpyHostToDevice, c->stream));   // the ONE upload
+    st = stage_crop_voxel(c, c->d_in, stride, n, 1, p, nullptr);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    if (c->h_fs[0].status != CD_OK) return fail(c, c->h_fs[0].status, "voxel grid: leaf size too small for the input extent");
+    std::vector<int> iters;
+    st = stage_plane(c, 1, p, iters, nullptr);
+    if (st) return st;
+    st = stage_extract(c, 1, p);
+    if (st) return st;
+    st = sync_fs(c, 1);
+    if (st) return st;
+    const int no = c->h_fs[0].n_o;
+    if (out_n_inliers) *out_n_inliers = c->h_fs[0].n_plane;
+    if (no > capacity) { *out_n = no; return fail(c, CD_ERR_CAPACITY, "output capacity too small"); }
+    const int rgb_off = (p->rgb_offset >= 12 && !(p->rgb_offset & 3) && (size_t)p->rgb_offset + 4 <= stride) ? p->rgb_offset : -1;
+    st = download_records(c, c->d_obj, no, stride, rgb_off, 0u, out_records, in_bytes);               // the ONE download
+    if (st) return st;
+    *out_n = no;
+    if (!c->h_have[0]) return CD_ERR_NO_MODEL;
+    coeff[0] = c->h_model[0].x; coeff[1] = c->h_model[0].y; coeff[2] = c->h_model[0].z; coeff[3] = c->h_model[0].w;
+    return CD_OK;
+}
+
+int cd_set_frame_guesses(cd_context* c, const float* guesses, int n_frames) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    if (n_frames < 0 || (n_frames > 0 && !guesses)) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    for (size_t i = 0; i < 16 * (size_t)n_frames; ++i)
+        if (!std::isfinite(guesses[i])) return fail(c, CD_ERR_INVALID_ARG, "a guess holds a non-finite value");
+    c->frame_guess.assign(guesses, guesses + 16 * (size_t)n_frames);
+    return CD_OK;
 }
 
 int cd_get_timing(const cd_context* c, cd_timing* out) {

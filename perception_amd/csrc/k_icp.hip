@@ -1658,6 +1658,30 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_fitness(const IcpWork* __r
     if (threadIdx.x == 0) atomicAdd(&accf[wk.cluster], s_acc);
 }
 
+// pcl::Registration::align(output, guess): input_transformed = guess * source before the first iteration (the iterations
+// then run on d_src as they do from the identity; final_transformation_ starts as the guess - the host puts it into the
+// initial IcpState).  guesses: one row-major 4x4 per frame (per_frame != 0) or a single one.
+__global__ void __launch_bounds__(BLOCK) k_icp_apply_guess(const IcpCluster* __restrict__ cl, const float* __restrict__ guesses,
+                                                           int per_frame, const float4* __restrict__ src0, float4* __restrict__ src) {
+    const IcpCluster c = cl[blockIdx.x];
+    const float* G = guesses + (per_frame ? 16 * (size_t)c.frame : 0);
+    float T[12];
+#pragma unroll
+    for (int k = 0; k < 12; ++k) T[k] = G[k];
+    for (int i = blockIdx.y * BLOCK + threadIdx.x; i < c.n; i += gridDim.y * BLOCK) {
+        const float4 p = src0[c.src_off + i];
+        float ox, oy, oz;
+        xform(T, p.x, p.y, p.z, ox, oy, oz);
+        src[c.src_off + i] = make_float4(ox, oy, oz, p.w);
+    }
+}
+void launch_icp_apply_guess(hipStream_t s, int ncl, int max_n, const IcpCluster* cl, const float* guesses, int per_frame,
+                            const float4* src0, float4* src) {
+    if (ncl <= 0 || max_n <= 0) return;
+    const int gx = (max_n + BLOCK - 1) / BLOCK;
+    hipLaunchKernelGGL(k_icp_apply_guess, dim3(ncl, gx < 64 ? gx : 64), dim3(BLOCK), 0, s, cl, guesses, per_frame, src0, src);
+}
+
 void launch_icp_iter(hipStream_t s, int it, int n_work, int ncl, const IcpWork* work, const IcpCluster* cl, IcpState* st,
                      unsigned long long* acc, const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
                      float4* src, int* nn, float* d2buf, int qslice, int* queue, int n_cu, IcpParams prm) {

@@ -339,6 +339,27 @@ __global__ void __launch_bounds__(BLOCK) k_gather_records(const uint32_t* __rest
     const int r = (int)(t / words), wd = (int)(t % words);
     out[t] = in[(size_t)idx[r] * words + wd];
 }
+// float4 points (x, y, z, packed rgb) -> records of `words` 4-byte words in a PointCloud2 layout: x,y,z in words 0..2, the
+// colour in word rgb_word (< 0: none), word 3 = pad3 when it is not the colour word (pcl::PointXYZ keeps 1.0f there and
+// pcl::toROSMsg ships the struct as it is), every other word zero.  One thread per output word: coalesced stores.
+__global__ void __launch_bounds__(BLOCK) k_pack_records(const float4* __restrict__ pts, int m, int words, int rgb_word, uint32_t pad3,
+                                                        uint32_t* __restrict__ out) {
+    const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (size_t)m * words) return;
+    const int r = (int)(t / words), wd = (int)(t % words);
+    const float4 p = pts[r];
+    uint32_t v = 0u;
+    if (wd == 0) v = __float_as_uint(p.x);
+    else if (wd == 1) v = __float_as_uint(p.y);
+    else if (wd == 2) v = __float_as_uint(p.z);
+    else if (wd == rgb_word) v = __float_as_uint(p.w);
+    else if (wd == 3) v = pad3;
+    out[t] = v;
+}
+void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out) {
+    const size_t tot = (size_t)m * words;
+    if (tot > 0) hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, pts, m, words, rgb_word, pad3, (uint32_t*)out);
+}
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag) {
     if (m > 0) hipLaunchKernelGGL(k_mark_indices, dim3((m + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, idx, m, n, flag);
 }

@@ -19,6 +19,7 @@ void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
 void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out);
 void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out);
+void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out);
 
 // k_sort.hip : segmented (per frame) stable LSD radix sort of (key, value) pairs, all passes
 constexpr int SORT_MAX_PASSES_HOST = 4;
@@ -66,6 +67,8 @@ void launch_icp_fitness(hipStream_t s, int n_work, const IcpWork* work, const Ic
                         int parity, unsigned long long* accf, const float4* tpl, const float4* tlo, const float4* thi,
                         const IcpGrid* grids, const float4* src0, int* nn, float* d2buf, int qslice);
 
+void launch_icp_apply_guess(hipStream_t s, int ncl, int max_n, const IcpCluster* cl, const float* guesses, int per_frame,
+                            const float4* src0, float4* src);
 void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
                      const float4* tpl, const float4* tlo, const float4* thi, const unsigned short* kdmap, const IcpGrid* grids,
                      const unsigned short* tcell, float4* src, const float4* src0, int* nn,

@@ -32,6 +32,19 @@ template <class M> const M* last(const std::string& topic) {
     return static_cast<const M*>(it->second.msg.get());
 }
 inline int count(const std::string& topic) { auto it = sent().find(topic); return it == sent().end() ? 0 : it->second.count; }
+// what a node's main() registered: advertised topics (with the message type), subscriptions (with the queue size), services
+struct Endpoint { std::string name; const std::type_info* type = nullptr; uint32_t queue = 0; };
+inline std::vector<Endpoint>& advertised() { static std::vector<Endpoint> v; return v; }
+inline std::vector<Endpoint>& subscribed() { static std::vector<Endpoint> v; return v; }
+inline std::vector<std::string>& services() { static std::vector<std::string> v; return v; }
+template <class M> bool advertises(const std::string& topic) {
+    for (const Endpoint& e : advertised()) if (e.name == topic && *e.type == typeid(M)) return true;
+    return false;
+}
+template <class M> bool subscribes(const std::string& topic, uint32_t queue) {
+    for (const Endpoint& e : subscribed()) if (e.name == topic && *e.type == typeid(M) && e.queue == queue) return true;
+    return false;
+}
 }  // namespace stub
 
 inline void init(int&, char**, const std::string&) {}
@@ -60,10 +73,10 @@ class NodeHandle {
     explicit NodeHandle(const std::string& ns = "") : ns_(ns) {}
     template <class T> bool param(const std::string& name, T& v, const T& def) const { if (stub::get(name, v)) return true; v = def; return false; }
     template <class T> bool getParam(const std::string& name, T& v) const { return stub::get(name, v); }
-    template <class M> Subscriber subscribe(const std::string&, uint32_t, void (*)(const std::shared_ptr<const M>&)) { return Subscriber(); }
-    template <class M> Subscriber subscribe(const std::string&, uint32_t, void (*)(const M&)) { return Subscriber(); }
-    template <class M> Publisher advertise(const std::string& topic, uint32_t) { return Publisher(topic); }
-    template <class Req, class Res> ServiceServer advertiseService(const std::string&, bool (*)(Req&, Res&)) { return ServiceServer(); }
+    template <class M> Subscriber subscribe(const std::string& t, uint32_t q, void (*)(const std::shared_ptr<const M>&)) { stub::subscribed().push_back({t, &typeid(M), q}); return Subscriber(); }
+    template <class M> Subscriber subscribe(const std::string& t, uint32_t q, void (*)(const M&)) { stub::subscribed().push_back({t, &typeid(M), q}); return Subscriber(); }
+    template <class M> Publisher advertise(const std::string& topic, uint32_t q) { stub::advertised().push_back({topic, &typeid(M), q}); return Publisher(topic); }
+    template <class Req, class Res> ServiceServer advertiseService(const std::string& name, bool (*)(Req&, Res&)) { stub::services().push_back(name); return ServiceServer(); }
   private:
     std::string ns_;
 };

@@ -1,0 +1,237 @@
+"""GPU parity of the round-3 C-ABI additions, against the CPU oracle:
+  * cd_get_frame_cloud / cd_get_cluster_points - the clouds object_pose_detection and iterative_closest_point publish
+    (opd.cpp:338-343, 257-262; icp.cpp:193-197), read back from the buffers a fused call leaves on the device;
+  * cd_ground_plane - ground_plane_segmentation's callback (gps.cpp:43-112) as one call;
+  * the opt-in initial guess of the registration (pcl::Registration::align(output, guess); icp.cpp:130-134,165-167),
+    in every ICP driver, through cd_icp, cd_params and cd_set_frame_guesses."""
+import numpy as np
+import pytest
+
+from conftest import rot_xyz
+from perception_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+POSE_TOL = 1e-4
+
+
+def _same_cluster(a, b):
+    assert (a.size, a.iterations, a.converged, a.accepted) == (b.size, b.iterations, b.converged, b.accepted)
+    assert list(a.T) == list(b.T), "final transformation not bit-identical"
+    assert a.fitness == b.fitness
+    assert np.linalg.norm(np.array(a.pose) - np.array(b.pose)) < POSE_TOL
+
+
+@pytest.fixture(scope="module")
+def ctx(template):
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=4)
+    c.set_template(0, template)
+    yield c
+    c.close()
+
+
+def test_frame_clouds_and_cluster_points_read_back(ctx, O, template, frames4):
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    batch = np.stack(frames4, 0)
+    res, _, _ = ctx.process_batch(batch, prm)
+    for f in range(4):
+        o = O.process_frame(frames4[f], prm, template, want_clouds=True, all_clusters=32)
+        st, vox, rgb, _, _ = O.crop_voxel(frames4[f], prm, want_rgb=True)
+        assert st == 0
+        # voxel cloud in the D435 / PointXYZRGB wire layout (32-byte records, rgb at 16) and as 16-byte x y z rgb
+        for stride, rgb_off in ((32, 16), (16, 12), (12, -1)):
+            rec = ctx.frame_cloud(f, capi.CD_CLOUD_VOXELS, stride, rgb_off)
+            assert rec.shape == (len(vox), stride // 4)
+            assert np.array_equal(rec[:, :3], vox.view(np.uint32))
+            if rgb_off >= 0:
+                assert np.array_equal(rec[:, rgb_off // 4], rgb)
+            rest = [w for w in range(3, stride // 4) if w != rgb_off // 4 or rgb_off < 0]
+            assert not rec[:, rest].any()
+        obj = ctx.frame_cloud(f, capi.CD_CLOUD_OBJECTS, 32, 16)
+        assert np.array_equal(obj[:, :3], o["objects"].view(np.uint32))
+        # its colours: those of the voxels that survived (objects are a subsequence of the voxel cloud)
+        keep = np.ones(len(vox), bool)
+        keep[o["plane_inliers"]] = False
+        keep &= ~((vox[:, 2].astype(np.float64) > prm.crop2_z_max) | (vox[:, 2].astype(np.float64) < prm.crop2_z_min))
+        assert np.array_equal(obj[:, 4], rgb[keep])
+        # clusters: as extracted, and as icp.align returned them (bit for bit the oracle's iterated cloud)
+        assert res[f].n_clusters == o["result"].n_clusters > 0
+        for k in range(res[f].n_clusters):
+            src = o["objects"][o["labels"] == k]
+            got = ctx.cluster_points(f, k, aligned=False)
+            assert got.shape == (len(src), 4) and np.array_equal(got[:, :3].view(np.uint32), src.view(np.uint32))
+            assert (got[:, 3] == 1.0).all()                      # pcl::PointXYZ::data[3] on the wire
+            s0, r0, al = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+            got = ctx.cluster_points(f, k, aligned=True, stride_bytes=12)
+            assert np.array_equal(got.view(np.uint32), al.view(np.uint32))
+    # errors: not a frame / cluster of the batch, capacity, and invalidation by any other compute call
+    with pytest.raises(capi.CuboidError):
+        ctx.frame_cloud(4, capi.CD_CLOUD_VOXELS)
+    with pytest.raises(capi.CuboidError):
+        ctx.cluster_points(0, res[0].n_clusters)
+    n = capi.C.c_int()
+    buf = np.zeros((4, 4), np.uint32)
+    st = ctx.lib.cd_get_frame_cloud(ctx.h, 0, capi.CD_CLOUD_VOXELS, buf.ctypes.data_as(capi.C.c_void_p), 16, 12, 4, capi.C.byref(n))
+    assert st == capi.CD_ERR_CAPACITY and n.value == res[0].n_voxels
+    ctx.crop_voxel(frames4[0], prm)
+    with pytest.raises(capi.CuboidError):
+        ctx.frame_cloud(0, capi.CD_CLOUD_VOXELS)
+    assert ctx.lib.cd_get_cluster_results(ctx.h, 0, 0, 0, None, None) == capi.CD_ERR_INVALID_ARG
+
+
+def test_cluster_points_with_several_templates(O, template, frames4, monkeypatch):
+    """Every cluster against two templates (template_slot = -1): the aligned cloud handed back is the one of the template
+    that won, whichever ICP stage layout the batch took."""
+    from perception_amd import templates
+    t2 = templates.template_xyz32(0.2, 0.075, 0.1, 0.005)
+    prm = capi.default_params()
+    prm.template_slot = -1
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=2)
+    try:
+        c.set_template(0, template)
+        c.set_template(3, t2)
+        res, _, _ = c.process_batch(np.stack(frames4[:2], 0), prm)
+        for f in range(2):
+            o = O.process_frame(frames4[f], prm, template, want_clouds=True)
+            for k in range(res[f].n_clusters):
+                src = o["objects"][o["labels"] == k]
+                best = None
+                for slot, t in ((0, template), (3, t2)):
+                    s0, r0, al = O.icp(t, src, prm, nn_mode=1, want_aligned=True)
+                    if best is None or r0.fitness < best[1].fitness:
+                        best = (slot, r0, al)
+                assert res[f].clusters[k].template_slot == best[0]
+                got = c.cluster_points(f, k, aligned=True, stride_bytes=12)
+                assert np.array_equal(got.view(np.uint32), best[2].view(np.uint32))
+    finally:
+        c.close()
+
+
+def test_ground_plane_one_call(ctx, O, frames4):
+    """cd_ground_plane == cd_crop_voxel + cd_segment_plane + ExtractIndices(negative) of gps.cpp:43-112, records in the
+    input's layout (here 16-byte x y z rgb and a 32-byte PointXYZRGB-like one)."""
+    for f, leaf, thr in ((0, 0.005, 0.015), (2, 0.01, 0.01)):
+        for words, rgb_off in ((4, 12), (8, 16)):
+            prm = capi.default_params()
+            prm.leaf_size, prm.plane_distance_threshold = leaf, thr
+            prm.crop2_enable = 0
+            prm.rgb_offset = rgb_off
+            frame = np.zeros((len(frames4[f]), words), np.float32)
+            frame[:, :3] = frames4[f][:, :3]
+            frame[:, rgb_off // 4] = frames4[f][:, 3]
+            if words > 4:
+                frame[:, 3] = 7.0          # junk in the padding of the input must not reach the output
+            st, coeff, rec, ni = ctx.ground_plane(frame, prm)
+            s0, vox, rgb, _, _ = O.crop_voxel(frame, prm, want_rgb=True)
+            s1, c1, inl, _ = O.segment_plane(vox, prm)
+            assert st == s0 == s1 == 0 and ni == len(inl)
+            keep = np.ones(len(vox), bool)
+            keep[inl] = False
+            assert rec.shape == (int(keep.sum()), words)
+            assert np.array_equal(rec[:, :3], vox[keep].view(np.uint32))
+            assert np.array_equal(rec[:, rgb_off // 4], rgb[keep])
+            rest = [w for w in range(3, words) if w != rgb_off // 4]
+            assert not rec[:, rest].any()
+            assert np.array_equal(coeff.view(np.uint32), c1.view(np.uint32))
+    # no plane: three collinear-free but tiny clouds fail in PCL as in the oracle; status NO_MODEL, every voxel comes back
+    prm = capi.default_params()
+    prm.crop2_enable = 0
+    prm.rgb_offset = -1
+    pts = np.array([[0.0, 0.0, 0.5, 0], [0.01, 0.0, 0.5, 0]], np.float32)
+    st, coeff, rec, ni = ctx.ground_plane(pts, prm)
+    s0, vox, _, _, _ = O.crop_voxel(pts, prm)
+    s1, _, inl, _ = O.segment_plane(vox, prm)
+    assert st == capi.CD_ERR_NO_MODEL and s1 == capi.CD_ERR_NO_MODEL and ni == 0
+    assert np.array_equal(rec[:, :3], vox.view(np.uint32))
+
+
+def _guess_for(o, k, template):
+    """a plausible prior: the template's frame moved onto the cluster's centroid with a small yaw error"""
+    src = o["objects"][o["labels"] == k]
+    G = np.eye(4)
+    G[:3, :3] = rot_xyz(0.0, 0.0, 0.05)
+    G[:3, 3] = -(G[:3, :3] @ src.mean(0).astype(np.float64)) + template.mean(0)
+    return G.astype(np.float32)
+
+
+def test_icp_guess_single_call(ctx, O, template, frames4):
+    prm = capi.default_params()
+    o = O.process_frame(frames4[0], prm, template, want_clouds=True)
+    src = o["objects"][o["labels"] == 0]
+    s0, base, _ = O.icp(template, src, prm, nn_mode=1)
+    G = _guess_for(o, 0, template)
+    prm.icp_use_guess = capi.CD_GUESS_PARAMS
+    prm.icp_guess[:] = list(G.ravel())
+    st, res, al = ctx.icp(0, src, prm, want_aligned=True)
+    s1, r1, a1 = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert st == s1 == 0
+    _same_cluster(res, r1)
+    assert np.array_equal(al.view(np.uint32), a1.view(np.uint32))
+    assert r1.iterations < base.iterations            # what the guess is for
+    # the identity as an explicit guess is the default path, bit for bit
+    prm.icp_guess[:] = list(np.eye(4, dtype=np.float32).ravel())
+    st, res, _ = ctx.icp(0, src, prm)
+    _same_cluster(res, base)
+    # validation
+    prm.icp_guess[5] = float("nan")
+    with pytest.raises(capi.CuboidError):
+        ctx.icp(0, src, prm)
+    prm.icp_use_guess = 7
+    with pytest.raises(capi.CuboidError):
+        ctx.icp(0, src, prm)
+
+
+@pytest.mark.parametrize("mode", ["auto", "sliced", "cluster", "pipe", "multi-launch"])
+def test_icp_guess_in_every_driver(O, template, frames4, monkeypatch, mode):
+    """Per-frame guesses through the fused call, under each ICP driver: records bit-identical to the oracle run with the
+    same guess, and the default (no guess) unchanged afterwards."""
+    if mode in ("sliced", "cluster", "pipe"):
+        monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    if mode == "multi-launch":
+        monkeypatch.setenv("CUBOID_ICP_PERSIST", "0")
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=4)
+    try:
+        c.set_template(0, template)
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        ref = [O.process_frame(f, prm, template, want_clouds=True) for f in frames4]
+        guesses = np.stack([_guess_for(ref[f], 0, template) for f in range(4)], 0)
+        prm.icp_use_guess = capi.CD_GUESS_PER_FRAME
+        with pytest.raises(capi.CuboidError):          # no guesses stored yet
+            c.process_batch(np.stack(frames4, 0), prm)
+        c.set_frame_guesses(guesses)
+        res, _, _ = c.process_batch(np.stack(frames4, 0), prm)
+        fewer = 0
+        for f in range(4):
+            po = capi.default_params()
+            po.rgb_offset = 12
+            po.icp_use_guess = capi.CD_GUESS_PARAMS
+            po.icp_guess[:] = list(guesses[f].ravel())
+            o = O.process_frame(frames4[f], po, template)["result"]
+            assert res[f].n_clusters == o.n_clusters
+            for k in range(o.n_clusters):
+                _same_cluster(res[f].clusters[k], o.clusters[k])
+            fewer += ref[f]["result"].clusters[0].iterations - o.clusters[0].iterations
+            if mode == "auto":                          # the aligned cloud includes the guess
+                src = ref[f]["objects"][ref[f]["labels"] == 0]
+                _, _, al = O.icp(template, src, po, nn_mode=1, want_aligned=True)
+                assert np.array_equal(c.cluster_points(f, 0, aligned=True, stride_bytes=12).view(np.uint32), al.view(np.uint32))
+        assert fewer > 0
+        # one frame (the latency path, k_icp_persist unless switched off) with the single guess of cd_params
+        po = capi.default_params()
+        po.rgb_offset = 12
+        po.icp_use_guess = capi.CD_GUESS_PARAMS
+        po.icp_guess[:] = list(guesses[1].ravel())
+        r1, _, _ = c.process_frame(frames4[1], po)
+        o = O.process_frame(frames4[1], po, template)["result"]
+        for k in range(o.n_clusters):
+            _same_cluster(r1.clusters[k], o.clusters[k])
+        # default again
+        prm.icp_use_guess = capi.CD_GUESS_NONE
+        res, _, _ = c.process_batch(np.stack(frames4, 0), prm)
+        for f in range(4):
+            for k in range(ref[f]["result"].n_clusters):
+                _same_cluster(res[f].clusters[k], ref[f]["result"].clusters[k])
+        c.set_frame_guesses(None)
+    finally:
+        c.close()
