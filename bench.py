@@ -29,7 +29,37 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak
-PMC_TRAFFIC_FILE = "r02_pmc_traffic.json"   # HBM bytes per dispatch from the separate --pmc FETCH_SIZE / WRITE_SIZE passes
+# Counter files of the current round under profiles/ (written by tools/profile_round.sh and tools/probe_icp_work.py on the
+# GPU box, copied into profiles/ and committed); the previous round's are the fallback until this round's exist.
+PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")   # HBM bytes per dispatch: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILES = ("r03_pmc_icp.txt", "r02_pmc_icp.txt")                   # SQ counters per kernel (four separate --pmc passes)
+ICP_WORK_FILES = ("r03_icp_work.json",)                                 # executed distance tests of the dominant kernel (-DCD_STATS build)
+WAVES_PER_SIMD_ICP = 4          # k_icp_pipe: one 1024-thread workgroup per CU = 16 waves = 4 per SIMD
+
+
+def _first_profile(names):
+    for n in names:
+        p = os.path.join(ROOT, "profiles", n)
+        if os.path.exists(p):
+            return n, p
+    return None, None
+
+
+def sq_counters(kernel):
+    """SQ counters of `kernel` from the committed PMC summary (lines "<kernel> {...} dispatches n" per pass)."""
+    import ast
+    name, path = _first_profile(PMC_SQ_FILES)
+    out = {}
+    if not path:
+        return None, out
+    for ln in open(path):
+        if ln.startswith(kernel + " {"):
+            try:
+                d = ast.literal_eval(ln[len(kernel) + 1:ln.rindex("}") + 1])
+                out.update({k: float(v) for k, v in d.items()})
+            except (ValueError, SyntaxError):
+                pass
+    return name, out
 
 
 def _render(i):
@@ -197,6 +227,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency measurement (BASELINE config 2; runs after the timed region)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed path's records (runs after the timed region)")
+    ap.add_argument("--guess", choices=("none", "sne", "track"), default="none",
+                    help="after the headline measurement, a separately labelled leg with per-frame initial guesses (opt-in ICP guess; "
+                         "reported under guess_leg, never part of value).  sne: the inverse of the cuboid frame of "
+                         "surface_normal_estimation, taken literally; track: the previous estimate of the frame's largest cluster, "
+                         "perturbed by 1 cm / 2 degrees (frame-to-frame tracking)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, gather their rank ids and rank 0 "
                          "prints them (tests/test_bench_launcher.py)")
@@ -326,6 +361,97 @@ def main():
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, 1, prm, results=one)
         lat.append((time.perf_counter() - a) * 1e3)
 
+    # Host-fed single frame (what a ROS callback gets: one H2D of the 4.9 MB blob, the chain, the results back), after the
+    # timed region: cd_process_frame with a host pointer, and ground_plane_segmentation's callback as ONE call (cd_ground_plane).
+    lat_host, lat_gp = [], []
+    if not args.no_latency and args.config == 3:
+        f0 = np.ascontiguousarray(frames[0])
+        gp = capi.default_params()
+        gp.rgb_offset = 12
+        gp.crop2_enable = 0
+        for _ in range(10):
+            a = time.perf_counter()
+            ctx.process_frame(f0, prm)
+            lat_host.append((time.perf_counter() - a) * 1e3)
+        for _ in range(10):
+            a = time.perf_counter()
+            ctx.ground_plane(f0, gp)
+            lat_gp.append((time.perf_counter() - a) * 1e3)
+
+    # Separately labelled leg, NOT part of `value`: the same batch with the registration started from a per-frame initial
+    # guess (cd_params.icp_use_guess, opt-in; the reference's authors meant to feed surface_normal_estimation's pose to
+    # ICP, icp.cpp:130-134,165-167).  --guess sne: guess of frame f = inverse of the cuboid frame cd_surface_frame finds
+    # in the frame's object cloud (three axis-constrained planes, sne.cpp:167-234), identity where it finds none.
+    guess_leg = None
+    if args.guess != "none" and args.config == 3:
+        fence()
+        res0 = (capi.CdFrameResult * F)()
+        ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res0)
+        clouds = [(ctx.frame_cloud(f, capi.CD_CLOUD_OBJECTS, 16, -1)[:, :3].copy().view(np.float32), np.array(res0[f].plane[:3], np.float32)) for f in range(F)]
+        base_it = [res0[f].clusters[k].iterations for f in range(F) for k in range(min(res0[f].n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME))]
+        base_acc = sum(res0[f].clusters[k].accepted for f in range(F) for k in range(min(res0[f].n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)))
+        guesses = np.tile(np.eye(4, dtype=np.float32), (F, 1, 1))
+        found = 0
+        sp = capi.default_params()
+        sp.plane_distance_threshold = 0.003      # the faces of a 30 mm cuboid must come apart (the launch value 0.015 is the table's)
+        t_sne = time.perf_counter()
+        if args.guess == "track":
+            c_, s_ = np.cos, np.sin
+            rx, ry, rz = 0.02, -0.015, 0.03
+            Rp = (np.array([[c_(rz), -s_(rz), 0], [s_(rz), c_(rz), 0], [0, 0, 1]]) @ np.array([[c_(ry), 0, s_(ry)], [0, 1, 0], [-s_(ry), 0, c_(ry)]])
+                  @ np.array([[1, 0, 0], [0, c_(rx), -s_(rx)], [0, s_(rx), c_(rx)]]))
+            P = np.eye(4)
+            P[:3, :3], P[:3, 3] = Rp, [0.008, -0.006, 0.005]
+            for f in range(F):
+                if res0[f].n_clusters > 0:
+                    guesses[f] = (P @ np.array(res0[f].clusters[0].T, np.float64).reshape(4, 4)).astype(np.float32)
+                    found += 1
+            clouds = []
+        for f, (obj, nrm) in enumerate(clouds):
+            if len(obj) < 10:
+                continue
+            st_s, rs = ctx.surface_frame(obj, nrm, sp)
+            if st_s != capi.CD_OK:
+                continue
+            Rt = np.array(rs.Rt, np.float64).reshape(4, 4)
+            if not np.isfinite(Rt).all() or abs(np.linalg.det(Rt[:3, :3])) < 1e-6:
+                continue
+            guesses[f] = np.linalg.inv(Rt).astype(np.float32)
+            found += 1
+        t_sne = time.perf_counter() - t_sne
+        gprm = capi.default_params()
+        gprm.rgb_offset = 12
+        gprm.icp_use_guess = capi.CD_GUESS_PER_FRAME
+        for cx in pipe.contexts:
+            cx.set_frame_guesses(guesses)
+        prm_saved, prm = prm, gprm
+        gsteps = max(10, args.steps // 3)
+        run_steps(2)
+        fence()
+        tg = time.perf_counter()
+        grec, _ = run_steps(gsteps)
+        fence()
+        tg = time.perf_counter() - tg
+        prm = prm_saved
+        for cx in pipe.contexts:
+            cx.set_frame_guesses(None)
+        gr = capi.results_from_array(grec)[rank * F:(rank + 1) * F]
+        g_it = [gr[f].clusters[k].iterations for f in range(F) for k in range(min(gr[f].n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME))]
+        g_acc = sum(gr[f].clusters[k].accepted for f in range(F) for k in range(min(gr[f].n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)))
+        guess_leg = {"guess": args.guess, "frames_per_s": F * gsteps / tg, "ms_per_step": tg / gsteps * 1e3, "steps": gsteps,
+                     "frames_with_a_guess": found, "frames": F, "guess_ms_per_frame_host_loop": t_sne / F * 1e3,
+                     "mean_iterations": float(np.mean(g_it)) if g_it else 0.0, "mean_iterations_identity_guess": float(np.mean(base_it)) if base_it else 0.0,
+                     "accepted": int(g_acc), "accepted_identity_guess": int(base_acc), "clusters": len(g_it),
+                     "note": ("opt-in path, outside the headline value: per-frame guess = inverse of cd_surface_frame's cuboid frame, taken literally "
+                              "(surface_normal_estimation.cpp:212-225 -> iterative_closest_point.cpp:130-134,165-167; plane threshold 3 mm); the "
+                              "frame it finds has its origin on a face and normals of arbitrary sign, which is not the template's frame: the "
+                              "registrations stop early in a wrong minimum (see accepted) - the reference leaves this path disabled"
+                              if args.guess == "sne" else
+                              "opt-in path, outside the headline value: per-frame guess = the final transformation of the frame's largest cluster "
+                              "from the identity-guess run, moved by 1 cm / 2 degrees (what a tracker hands over from the previous frame); a "
+                              "frame's other clusters start from the same matrix") +
+                             "; the guesses are computed before this leg's timed region"}
+
     # Self-check of the timed path, outside the timed region: the records of the LAST timed step (k_icp_pipe with refilled
     # slots, other batches in flight, gathered over all ranks) must be byte-identical to a strictly serial pass of this
     # rank's batch on an otherwise idle GPU.
@@ -362,12 +488,41 @@ def main():
         # template does not fit LDS); sliced mode: one k_icp_iter per iteration
         whole = icp_launches == args.steps
         icp_kernel = ("k_icp_cluster" if os.environ.get("CUBOID_ICP_MODE") == "cluster" else "k_icp_pipe") if whole else "k_icp_iter"
+        traffic_file, tpath = _first_profile(PMC_TRAFFIC_FILES)
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", PMC_TRAFFIC_FILE)))
+            pmc = json.load(open(tpath))
             if F == 256 and N == 307200:
                 traffic = pmc["kernels"][icp_kernel]["hbm_bytes_per_dispatch"]
-        except (OSError, KeyError, ValueError):
+        except (OSError, KeyError, ValueError, TypeError):
             pass
+        # What bounds the dominant kernel, from its SQ counters: vector-ALU issue when the waves of a SIMD together keep
+        # its issue port busy most of the time (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is per wave; x waves per SIMD).
+        sq_file, sq = sq_counters(icp_kernel)
+        valu = None
+        bound = "hbm"
+        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU") and args.config == 3:
+            issue = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * WAVES_PER_SIMD_ICP
+            valu = {"issue_frac": issue, "counters_file": "profiles/" + sq_file,
+                    "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"],
+                    "waves_per_simd": WAVES_PER_SIMD_ICP,
+                    "salu_per_valu": (sq.get("SQ_INSTS_SALU", 0.0) / sq["SQ_INSTS_VALU"]) if sq.get("SQ_INSTS_VALU") else None,
+                    "wait_any_frac": (sq.get("SQ_WAIT_INST_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_INST_ANY") else None,
+                    "lds_bank_conflict_frac": (sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None}
+            wname, wpath = _first_profile(ICP_WORK_FILES)
+            if wpath:
+                try:
+                    w = json.load(open(wpath))
+                    fl = float(w["executed_flops"])
+                    valu.update({"work_file": "profiles/" + wname, "executed_pair_tests": w["executed_pair_tests"]["total"],
+                                 "flops_per_test": w["flops_per_pair_test"], "executed_flops_per_launch": fl,
+                                 "achieved_tflops": fl / (avg_launch_ms * 1e-3) / 1e12,
+                                 "frac_of_157.3_TFLOPs": fl / (avg_launch_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
+                                 "note": "distance and box arithmetic only (8 / 17 flops per test); the rest of the issue slots goes to "
+                                         "key packing, 64-bit compares, address arithmetic, control flow and the fixed-point moments"})
+                except (OSError, KeyError, ValueError):
+                    pass
+            if issue >= 0.6:
+                bound = "valu"
         out = {
             "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -385,17 +540,18 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "batches_in_flight": M,
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
-            "roofline": {"kernel": icp_kernel, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"kernel": icp_kernel, "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "note": "dominant kernel by time; its search is f32-VALU issue bound, not HBM bound - see icp_search and DESIGN.md section 4"},
+                         "valu": valu,
+                         "note": "achieved/peak/frac: algorithmic bytes of the dominant kernel over its HIP-event duration against the HBM peak, as the "
+                                 "contract defines them; `bound` is what the SQ counters say limits it (valu: f32 vector issue, see roofline.valu - its "
+                                 "working set is LDS/L2-resident), DESIGN.md section 4"},
             "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
-                           "note": "exact search: ~77 % of the queries walk a few cells of the template's uniform grid (lane per query), "
-                                   "the rest use run-box pruning (wave per query), so the brute-force-equivalent rate is not executed "
-                                   "work; the kernel is f32-VALU issue bound (SQ_ACTIVE_INST_VALU ~ 4 waves x 18.5 % = 74 % per SIMD, "
-                                   "profiles/r01c_pmc_icp.txt)",
+                           "note": "exact search by pruning (lane-per-query grid walk for near queries, wave-per-query k-d patch search for far ones): "
+                                   "the brute-force-equivalent rate is NOT executed work; executed tests and the issue-slot occupancy are in roofline.valu",
                            "fp32_valu_peak_tflops": FP32_VALU_PEAK_TFLOPS},
             "pipeline_hbm": {"algorithmic_bytes_per_frame": balg / F, "achieved_GBps": balg / F * value / world / 1e9,
                              "frac_of_peak": balg / F * value / world / 1e9 / HBM_PEAK_GBS},
@@ -407,6 +563,12 @@ def main():
             "single_frame_ms": ({"median": float(np.median(lat[2:])), "min": float(np.min(lat[2:])),
                                  "note": "BASELINE config 2: one frame, full chain, device-resident input, host wall clock of the "
                                          "synchronous C-ABI call; measured after the timed region"} if len(lat) > 2 else None),
+            "single_frame_ms_host": ({"process_frame_median": float(np.median(lat_host[2:])), "process_frame_min": float(np.min(lat_host[2:])),
+                                      "ground_plane_median": float(np.median(lat_gp[2:])), "ground_plane_min": float(np.min(lat_gp[2:])),
+                                      "note": "host-fed: pageable host buffer in (4.9 MB H2D), results out; cd_process_frame = the whole chain, "
+                                              "cd_ground_plane = ground_plane_segmentation's callback (gps.cpp:43-112) as one call incl. the download of "
+                                              "the kept records; host wall clock of the synchronous C-ABI call"} if len(lat_host) > 2 else None),
+            "guess_leg": guess_leg,
             "verified": verified,
             "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "
                              "byte-identical to a strictly serial pass run after the timed region",

@@ -308,6 +308,10 @@ typedef struct cd_timing {
                                                    * multi-launch loop (same results, tens of ms slower): 0 in a healthy run           */
     int64_t algorithmic_bytes;                    /* B_alg of SURVEY 8(d) for this batch */
     int64_t icp_algorithmic_bytes;                /* the S6 term of B_alg: sum 12*M + 12*N_s*(I_c+1) */
+    int32_t scan_retries;                         /* 1 when this call was redone because a chained scan stalled (several contexts on one
+                                                   * GPU can block each other's ordered compactions; the redo runs with the device to
+                                                   * itself): 0 in a healthy run                                                        */
+    int32_t reserved;
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

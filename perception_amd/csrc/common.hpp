@@ -30,6 +30,8 @@ constexpr int ICP_TPL_LDS = 7616;          // template points resident in LDS (1
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS
+constexpr int ICP_BIG_MAX = 65535;          // largest template the persistent kernel searches in global memory (16-bit positions in the keys)
+constexpr int ICP_BIG_PATCHES = 1024;      // its k-d patches of 64 points (boxes in LDS, 32 KiB)
 constexpr int ICP_QSLICE = 512;            // max ICP source points (queries) per work item / workgroup
 
 // Per-frame scalars that live on the device and are mirrored to pinned host memory.
@@ -104,6 +106,14 @@ struct IcpGrid {
     int32_t chunk_start[ICP_MAX_CHUNKS], chunk_n[ICP_MAX_CHUNKS];
     int32_t pad2[3];
     float chunk_lo[ICP_MAX_CHUNKS][4], chunk_hi[ICP_MAX_CHUNKS][4];
+};
+
+// Second level over the k-d patch boxes of a template that does not fit LDS (k_icp_pipe_big): the k-d subtrees of at most 64
+// patches whose parent is larger ("superpatches": at most 64 of them for 1024 patches), each a run of consecutive patches.
+struct IcpSuper {
+    int32_t n;
+    int32_t first[64], cnt[64];   // first patch and number of patches
+    float lo[64][4], hi[64][4];   // box
 };
 
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity

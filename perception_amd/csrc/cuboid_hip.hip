@@ -10,7 +10,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <atomic>
 #include <mutex>
+#include <shared_mutex>
 #include <random>
 #include <vector>
 
@@ -63,15 +65,23 @@ struct cd_context {
     int* h_wgtab = nullptr;                                       // its pinned staging copy (3 * 1024 ints)
     int* h_ctl = nullptr;                                         // pinned: control words of k_icp_persist going up [0..7], coming back [8]
     std::vector<IcpState> st_init;                                // initial ICP states of a persistent launch (kept in case it gives up)
+    int force_stall = 0;                                          // CUBOID_FORCE_SCAN_STALL=n: the next n chained-scan checks report a stall (tests the retry)
+    int scan_retries = 0;                                         // calls of this context that were redone because a chained scan stalled
     int persist_gave_up = 0;                                      // persistent launches of this context that handed over to the multi-launch loop
     int n_cu = 256;
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
+    int icp_cpw = 1;                                              // clusters per workgroup a persistent ICP launch is sized for (CUBOID_ICP_CPW): 2 fills both pipeline slots
+    int icp_big_weight = 2;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     std::shared_ptr<const struct PreparedTemplate> tpl_prep[CD_MAX_TEMPLATES];   // host copies (shared across contexts)
     int tpl_off[CD_MAX_TEMPLATES] = {0}, tpl_m[CD_MAX_TEMPLATES] = {0};
-    bool tpl_gridded[CD_MAX_TEMPLATES] = {false};                // slot has a cell start table (fits LDS)
+    bool tpl_gridded[CD_MAX_TEMPLATES] = {false};                // slot has a cell start table
+    bool tpl_big[CD_MAX_TEMPLATES] = {false};                    // slot does not fit LDS but has what k_icp_pipe_big needs (cell table, k-d map, superpatches)
+    IcpSuper* d_super = nullptr;                                  // per template slot
+    hipStream_t stream2 = nullptr;                                // the second persistent ICP launch of a mixed-template batch runs beside the first
+    hipEvent_t ev2[2] = {nullptr, nullptr};
     // ICP
     IcpCluster *d_cl = nullptr, *h_cl = nullptr;
     IcpWork *d_work = nullptr, *h_work = nullptr, *d_work2 = nullptr, *h_work2 = nullptr;
@@ -131,6 +141,49 @@ int fail(cd_context* c, int code, const char* msg) {
     return code;
 }
 
+// ---- chained scans and several contexts on one GPU ---------------------------------------------------------------------------
+// A chained scan (crop, radix scatters, voxel heads, cd_extract) waits for tiles with smaller ids.  Within ONE grid that is
+// safe: every XCD starts its share of the workgroups in id order, so the unfinished tile with the smallest id is always
+// running or next in line on an XCD that holds nothing but finished-or-running tiles of the same grid.  With several
+// contexts in flight (BatchPipeline) the argument has a hole: grid A's waiting workgroups can fill the XCD that grid B's
+// next tile needs while B's fill the one A needs.  The waits are bounded (common.hpp), the kernel then reports
+// scan_stalled, and the call is REDONE ALONE: every compute call holds this per-device lock shared, the retry exclusively,
+// so no other context of the process has a kernel in flight while it runs.  (Never seen on hardware; CUBOID_FORCE_SCAN_STALL
+// exercises the path.)
+constexpr int CD_INTERNAL_STALL = -100;   // never leaves the library
+constexpr int MAX_DEVICES = 16;
+std::shared_mutex g_scan_mu[MAX_DEVICES];
+std::atomic<int> g_calls_in_flight[MAX_DEVICES];
+
+struct CallGuard {   // one per compute call: counts the contexts at work on the device (k_icp_persist wants the chip to itself)
+    int dev;
+    explicit CallGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_calls_in_flight[dev].fetch_add(1); }
+    ~CallGuard() { g_calls_in_flight[dev].fetch_sub(1); }
+};
+
+template <class Fn>
+int with_scan_retry(cd_context* c, Fn&& fn) {
+    const int dev = c->device & (MAX_DEVICES - 1);
+    int st;
+    {
+        std::shared_lock<std::shared_mutex> lk(g_scan_mu[dev]);
+        CallGuard g(dev);
+        st = fn();
+    }
+    if (st != CD_INTERNAL_STALL) return st;
+    if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: %s - redoing the call with the device to itself\n", c->err);
+    c->scan_retries += 1;
+    hipStreamSynchronize(c->stream);
+    {
+        std::unique_lock<std::shared_mutex> lk(g_scan_mu[dev]);
+        CallGuard g(dev);
+        st = fn();
+    }
+    c->timing.scan_retries = 1;
+    if (st == CD_INTERNAL_STALL) return fail(c, CD_ERR_DEVICE, "a chained scan stalled twice, the second time with the device to itself");
+    return st;
+}
+
 template <class Tp>
 hipError_t dalloc(Tp** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp)); }
 template <class Tp>
@@ -187,7 +240,8 @@ int sync_fs(cd_context* c, int F) {
     HIPCHK(c, hipMemcpyAsync(c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int f = 0; f < F; ++f)
-        if (c->h_fs[f].scan_stalled) return fail(c, CD_ERR_DEVICE, "a chained scan stalled (workgroups of a grid were not started in id order)");
+        if (c->h_fs[f].scan_stalled) return fail(c, CD_INTERNAL_STALL, "a chained scan stalled (workgroups of a grid were not started in id order)");
+    if (c->force_stall > 0) { c->force_stall -= 1; return fail(c, CD_INTERNAL_STALL, "a chained scan stalled (forced: CUBOID_FORCE_SCAN_STALL)"); }
     return CD_OK;
 }
 
@@ -460,28 +514,34 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // every template).  With several templates in the batch, the groups whose template is LDS-resident and gridded go through
     // ONE k_icp_pipe launch (each group gets a share of the workgroups and its own queue) when there are enough of them to
     // fill a fifth of the chip; the other clusters take the sliced driver below.
-    struct TplGroup { int beg, end, live; bool pipe; long long pts; };
+    // kind: 0 = no persistent kernel can take the template, 1 = k_icp_pipe (LDS-resident, gridded), 2 = k_icp_pipe_big (global memory)
+    struct TplGroup { int beg, end, live; int kind; long long pts; };
+    auto kind_of = [&](const IcpCluster& cl) -> int {
+        if (cl.tpl_m <= 0 || !c->tpl_gridded[cl.slot]) return 0;
+        if (cl.tpl_m <= ICP_TPL_LDS) return 1;
+        return c->tpl_big[cl.slot] ? 2 : 0;
+    };
     std::vector<TplGroup> groups;
     for (int k = 0; k < ncl; ++k) {
         const IcpCluster& cl = c->h_cl[k];
         if (groups.empty() || c->h_cl[groups.back().beg].tpl_off != cl.tpl_off || c->h_cl[groups.back().beg].tpl_m != cl.tpl_m)
-            groups.push_back(TplGroup{k, k, 0, cl.tpl_m > 0 && cl.tpl_m <= ICP_TPL_LDS && c->tpl_gridded[cl.slot] != 0, 0});
+            groups.push_back(TplGroup{k, k, 0, kind_of(cl), 0});
         TplGroup& g = groups.back();
         g.end = k + 1;
         if (cl.n >= 3) { g.live += 1; g.pts += cl.n; }
     }
     int n_grouped = 0;
-    for (const TplGroup& g : groups) if (g.pipe) n_grouped += g.live;
+    for (const TplGroup& g : groups) if (g.kind) n_grouped += g.live;
     const bool grouped_pipe = groups.size() > 1 && groups.size() <= 16 && n_grouped > 0 &&
                               (c->icp_mode == 3 || (c->icp_mode == 0 && n_grouped * 5 >= c->n_cu));
     if (std::getenv("CUBOID_DEBUG")) {
         std::fprintf(stderr, "cuboid_hip: stage_icp %d clusters, %zu template groups, %d in pipe groups, grouped_pipe %d:", ncl, groups.size(), n_grouped, (int)grouped_pipe);
-        for (const TplGroup& g : groups) std::fprintf(stderr, " [%d,%d) m=%d pipe=%d live=%d", g.beg, g.end, c->h_cl[g.beg].tpl_m, (int)g.pipe, g.live);
+        for (const TplGroup& g : groups) std::fprintf(stderr, " [%d,%d) m=%d kind=%d live=%d", g.beg, g.end, c->h_cl[g.beg].tpl_m, g.kind, g.live);
         std::fprintf(stderr, "\n");
     }
     std::vector<char> in_pipe((size_t)ncl, 0);
     if (grouped_pipe)
-        for (const TplGroup& g : groups) if (g.pipe) for (int k = g.beg; k < g.end; ++k) in_pipe[(size_t)k] = 1;
+        for (const TplGroup& g : groups) if (g.kind) for (int k = g.beg; k < g.end; ++k) in_pipe[(size_t)k] = 1;
     int nwork = 0;
     for (int k = 0; k < ncl; ++k) {
         IcpCluster& cl = c->h_cl[k];
@@ -519,39 +579,63 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
     // The pipelined variant (two clusters in flight per workgroup, no barrier in the iteration loop) needs one
     // LDS-resident gridded template shared by every cluster of the launch; otherwise k_icp_cluster runs.
-    bool pipe_ok = c->icp_mode != 2 && c->h_cl[0].tpl_m > 0 && c->h_cl[0].tpl_m <= ICP_TPL_LDS && c->tpl_gridded[c->h_cl[0].slot];
-    for (int k = 1; k < ncl && pipe_ok; ++k) pipe_ok = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
+    bool one_tpl = true;
+    for (int k = 1; k < ncl && one_tpl; ++k) one_tpl = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;
+    const bool pipe_ok = c->icp_mode != 2 && one_tpl && kind_of(c->h_cl[0]) == 1;
+    // ... or, for a template that does not fit LDS, its twin that reads the template from global memory (k_icp_pipe_big)
+    const bool big_ok = c->icp_mode != 2 && one_tpl && kind_of(c->h_cl[0]) == 2;
     // (auto mode: only the pipelined kernel beats the sliced driver; with mixed or non-resident templates k_icp_cluster's
     // barrier per iteration costs more than it saves, so those batches stay sliced unless the mode is forced)
     // (measured crossover on the bench frames: 33 clusters 3.3 ms sliced / 3.7 ms pipelined, 65 clusters 4.4 / 3.9, 130 clusters
     // 6.4 / 4.0: the pipelined kernel wins from about a fifth of the CUs' worth of clusters)
-    const bool whole_cluster = !grouped_pipe && (c->icp_mode >= 2 || (c->icp_mode == 0 && ncl * 5 >= c->n_cu && pipe_ok));
+    const bool whole_cluster = !grouped_pipe && (c->icp_mode >= 2 || (c->icp_mode == 0 && ncl * 5 >= c->n_cu && (pipe_ok || big_ok)));
     if (grouped_pipe) {
-        // items of `order`: the pipe groups one after the other, each largest cluster first
+        // items of `order`: the pipe groups one after the other (those of k_icp_pipe first, then those of k_icp_pipe_big),
+        // each largest cluster first.  The two kernels are launched side by side (second stream): their workgroups share the
+        // chip, every group gets workgroups in proportion to its points (a query against a template in global memory
+        // counted BIG_WEIGHT times), at least one, no more than it has clusters.
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
+        const long long BIG_WEIGHT = std::max(1, c->icp_big_weight);
+        const int cpw = std::max(1, c->icp_cpw);
         int* tab = c->h_wgtab;   // pinned: the copy below is asynchronous
         int ntab = 0;
         long long pts_all = 0;
         int npg = 0;
-        for (const TplGroup& g : groups) if (g.pipe && g.live > 0) { pts_all += g.pts; ++npg; }
-        int no = 0, gq = 0, n_wg = 0;
-        for (const TplGroup& g : groups) {
-            if (!g.pipe || g.live == 0) continue;
-            const int b = no;
-            for (int k = g.beg; k < g.end; ++k) if (c->h_cl[k].n >= 3) c->h_order[no++] = k;
-            std::stable_sort(c->h_order + b, c->h_order + no, [&](int x, int y) { return c->h_cl[x].n > c->h_cl[y].n; });
-            // workgroups in proportion to the group's points, at least one, no more than it has clusters
-            int share = (int)((long long)wg_cap * g.pts / std::max(pts_all, 1ll));
-            share = std::max(1, std::min(share, std::min(g.live, wg_cap - n_wg - (npg - 1 - gq))));
-            for (int w = 0; w < share && ntab + 3 <= 3 * 1024; ++w) { tab[ntab++] = b; tab[ntab++] = no; tab[ntab++] = gq; }
-            n_wg += share;
-            ++gq;
+        for (const TplGroup& g : groups) if (g.kind && g.live > 0) { pts_all += g.pts * (g.kind == 2 ? BIG_WEIGHT : 1); ++npg; }
+        int no = 0, gq = 0, n_wg = 0, wg_of[3] = {0, 0, 0}, tab_of[3] = {0, 0, 0};
+        for (int kind = 1; kind <= 2; ++kind) {
+            tab_of[kind] = ntab;
+            for (const TplGroup& g : groups) {
+                if (g.kind != kind || g.live == 0) continue;
+                const int b = no;
+                for (int k = g.beg; k < g.end; ++k) if (c->h_cl[k].n >= 3) c->h_order[no++] = k;
+                std::stable_sort(c->h_order + b, c->h_order + no, [&](int x, int y) { return c->h_cl[x].n > c->h_cl[y].n; });
+                int share = (int)((long long)wg_cap * g.pts * (kind == 2 ? BIG_WEIGHT : 1) / std::max(pts_all, 1ll));
+                share = std::max(1, std::min(share, std::min((g.live + cpw - 1) / cpw, wg_cap - n_wg - (npg - 1 - gq))));
+                for (int w = 0; w < share && ntab + 3 <= 3 * 1024; ++w) { tab[ntab++] = b; tab[ntab++] = no; tab[ntab++] = gq; }
+                n_wg += share;
+                wg_of[kind] += share;
+                ++gq;
+            }
         }
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
-        LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                        c->d_queue, n_wg, c->d_wgtab, ip));
+        const bool side = wg_of[1] > 0 && wg_of[2] > 0;
+        if (side) {   // everything uploaded so far is visible to the second stream
+            HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
+        }
+        if (wg_of[1] > 0)
+            LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+                            c->d_queue, wg_of[1], c->d_wgtab + tab_of[1], ip));
+        if (wg_of[2] > 0)
+            LAUNCH(c, launch_icp_pipe_big(side ? c->stream2 : c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid,
+                                c->d_super, c->d_tcell, c->d_src, c->d_src0, c->d_nn, c->d_queue, wg_of[2], c->d_wgtab + tab_of[2], ip));
+        if (side) {
+            HIPCHK(c, hipEventRecord(c->ev2[1], c->stream2));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[1], 0));
+        }
         c->timing.icp_kernel_launches = 1;
         if (nwork == 0) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -579,7 +663,10 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                            c->d_queue, std::min(ncl, wg_cap), nullptr, ip));
+                            c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
+        else if (big_ok)
+            LAUNCH(c, launch_icp_pipe_big(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_super, c->d_tcell,
+                                c->d_src, c->d_src0, c->d_nn, c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
         else
             LAUNCH(c, launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                                c->d_queue, wg_cap, ip));
@@ -604,7 +691,10 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // Few clusters: ONE persistent launch runs every iteration and the fitness pass (k_icp_persist: grid barrier per
     // iteration instead of two kernel launches).  Needs all its workgroups resident together; a barrier that does not
     // complete in time makes it give up, and the multi-launch loop below takes over from the initial state.
-    if (nwork > 0 && c->icp_persist) {
+    // (with other contexts at work - BatchPipeline - their persistent kernels hold the CUs this launch's grid barrier needs:
+    // it would wait, give up and hand over; go straight to the multi-launch loop then)
+    const bool siblings = g_calls_in_flight[c->device & (MAX_DEVICES - 1)].load() > 1;
+    if (nwork > 0 && c->icp_persist && (!siblings || c->icp_persist == 2)) {
         const int G = std::min(nwork, c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu);
         // measured against the multi-launch loop: 1 frame 1.50 / 1.78 ms, 4 frames 1.94 / 2.36, 8 frames 3.04 / 2.66 - with many
         // clusters the launch lasts as long as the slowest one while finished workgroups wait at the barriers, and a workgroup
@@ -1060,6 +1150,9 @@ void cd_destroy(cd_context* c) {
     for (void* p : dev) if (p) hipFree(p);
     if (c->d_koffx) hipFree(c->d_koffx);
     if (c->d_guess) hipFree(c->d_guess);
+    if (c->d_super) hipFree(c->d_super);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    for (auto& e : c->ev2) if (e) hipEventDestroy(e);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf, c->h_wgtab, c->h_ctl};
     for (void* p : host) if (p) hipHostFree(p);
     for (auto& e : c->ev) if (e) hipEventDestroy(e);
@@ -1102,6 +1195,9 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_rank, FN) == hipSuccess && dalloc(&c->d_cand, FN) == hipSuccess && dalloc(&c->d_sizes, FN) == hipSuccess && dalloc(&c->d_label, FN) == hipSuccess;
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
+    ok = ok && dalloc(&c->d_super, (size_t)CD_MAX_TEMPLATES) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    for (auto& e : c->ev2) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_grid, (size_t)CD_MAX_TEMPLATES) == hipSuccess && dalloc(&c->d_tcell, (size_t)CD_MAX_TEMPLATES * ICP_CELL_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_kdmap, (size_t)c->tpl_cap) == hipSuccess;
@@ -1118,8 +1214,11 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(1, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(1, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_FORCE_SCAN_STALL")) c->force_stall = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
@@ -1152,6 +1251,8 @@ struct PreparedTemplate {
     std::vector<unsigned short> kdmap;                   // patch order -> cell-sorted position (LDS-resident templates)
     std::vector<unsigned short> cell_start;              // grid start table (LDS-resident templates)
     IcpGrid grid;                                        // cell_off is set per slot at upload
+    IcpSuper super;                                      // second box level of a template that does not fit LDS (n = 0: none)
+    bool big_ok = false;                                 // k_icp_pipe_big can search it
 };
 
 static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz, size_t stride, int m) {
@@ -1186,6 +1287,7 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
     for (int a = 0; a < 3; ++a) if (!(gmn[a] <= gmx[a])) gmn[a] = gmx[a] = 0.f;
     IcpGrid& grid = P->grid;
     std::memset(&grid, 0, sizeof(grid));
+    std::memset(&P->super, 0, sizeof(P->super));
     {
         // point spacing: median nearest-neighbour distance of a sample of (at most 64 of) the points
         std::vector<float> nn2;
@@ -1229,7 +1331,7 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
             t.cid = (coord(t.z, grid.oz, grid.nz) * grid.ny + coord(t.y, grid.oy, grid.ny)) * grid.nx + coord(t.x, grid.ox, grid.nx);
         }
         std::sort(tp.begin(), tp.end(), [](const TP& a, const TP& bb) { return a.cid < bb.cid || (a.cid == bb.cid && a.oi < bb.oi); });
-        if (m <= ICP_TPL_LDS) {
+        if (m <= ICP_BIG_MAX) {   // (uint16 positions: templates the persistent kernels can walk)
             grid.ncell = ncell;
             P->cell_start.assign((size_t)ncell + 1, 0);
             int i = 0;
@@ -1242,7 +1344,12 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
     // one layout = the points (original index in .w) and the axis-aligned box of every run of 64 consecutive STORED
     // points (exact float min/max)
     auto layout = [&](std::vector<float4>& pts, std::vector<float4>& lo, std::vector<float4>& hi) {
-        pts.resize((size_t)m);
+        // (the last run is filled up with points at +inf, original index INT_MAX: kernels that read a whole run from global
+        // memory - k_icp_pipe_big - meet them as candidates that can never win)
+        const int imax = 0x7fffffff;
+        float wpad;
+        std::memcpy(&wpad, &imax, 4);
+        pts.assign((size_t)m_pad, make_float4(INFINITY, INFINITY, INFINITY, wpad));
         for (int i = 0; i < m; ++i) {
             float w;
             std::memcpy(&w, &tp[(size_t)i].oi, 4);
@@ -1265,6 +1372,7 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
     std::vector<int> pos_cell((size_t)m);                             // original index -> position in layout 1
     for (int i = 0; i < m; ++i) pos_cell[(size_t)tp[(size_t)i].oi] = i;
     std::vector<std::pair<int, int>> chunks;  // k-d subtrees of <= ICP_TPL_LDS points whose parent is larger (templates that do not fit LDS)
+    std::vector<std::pair<int, int>> supers;  // k-d subtrees of <= 64 patches whose parent is larger (same templates: IcpSuper)
     {
         // Layout 2, for the wave-per-query search: compact patches of 64 points from k-d median splits whose left part is
         // a multiple of 64, so that consecutive runs of 64 stored points have the smallest boxes the run-box pruning can get.
@@ -1278,6 +1386,11 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
                 bool inside = false;   // already inside a recorded chunk?
                 for (const auto& ch : chunks) inside = inside || (lo >= ch.first && hi <= ch.second);
                 if (!inside) chunks.push_back({lo, hi});
+            }
+            if (m > ICP_TPL_LDS && n <= 64 * ICP_SUB) {
+                bool inside = false;
+                for (const auto& su : supers) inside = inside || (lo >= su.first && hi <= su.second);
+                if (!inside) supers.push_back({lo, hi});
             }
             if (n <= ICP_SUB) {
                 std::sort(tp.begin() + lo, tp.begin() + hi, [](const TP& a, const TP& bb) { return a.oi < bb.oi; });
@@ -1338,11 +1451,36 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
             grid.half_lo[h][3] = grid.half_hi[h][3] = 0.f;
         }
     }
-    if (m <= ICP_TPL_LDS) {
+    if (m <= ICP_BIG_MAX) {
         // k-d patch r = the cell-sorted positions kdmap[64 r .. 64 r + 63]: the pipelined kernel searches far queries
-        // patch by patch THROUGH this table (compact boxes) while the points themselves stay cell-sorted in LDS
-        P->kdmap.assign((size_t)m_pad, (unsigned short)m_pad);   // padding -> the +inf pad run
+        // patch by patch THROUGH this table (compact boxes) while the points themselves stay cell-sorted in LDS; for a
+        // template in global memory (k_icp_pipe_big) it turns the position of a k-d ordered point into its cell-sorted one
+        P->kdmap.assign((size_t)m_pad, (unsigned short)std::min(m_pad, 65535));   // padding -> the +inf pad run
         for (int i = 0; i < m; ++i) P->kdmap[(size_t)i] = (unsigned short)pos_cell[(size_t)tp[(size_t)i].oi];
+    }
+    if (m > ICP_TPL_LDS && m <= ICP_BIG_MAX && m_pad / ICP_SUB <= ICP_BIG_PATCHES && !supers.empty() && supers.size() <= 64 && grid.ncell > 0) {
+        std::sort(supers.begin(), supers.end());
+        IcpSuper& su = P->super;
+        su.n = (int)supers.size();
+        bool ok = true;
+        int covered = 0;
+        for (int k = 0; k < su.n; ++k) {
+            const int lo = supers[(size_t)k].first, hi = supers[(size_t)k].second;
+            ok = ok && lo % ICP_SUB == 0 && lo == covered;   // runs of whole patches that tile the template
+            covered = hi;
+            su.first[k] = lo / ICP_SUB;
+            su.cnt[k] = (hi - lo + ICP_SUB - 1) / ICP_SUB;
+            float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+            for (int r = su.first[k]; r < su.first[k] + su.cnt[k]; ++r) {
+                const float lo3[3] = {P->kd_lo[(size_t)r].x, P->kd_lo[(size_t)r].y, P->kd_lo[(size_t)r].z};
+                const float hi3[3] = {P->kd_hi[(size_t)r].x, P->kd_hi[(size_t)r].y, P->kd_hi[(size_t)r].z};
+                for (int a = 0; a < 3; ++a) { mn[a] = std::fmin(mn[a], lo3[a]); mx[a] = std::fmax(mx[a], hi3[a]); }
+            }
+            for (int a = 0; a < 3; ++a) { su.lo[k][a] = mn[a]; su.hi[k][a] = mx[a]; }
+            su.lo[k][3] = su.hi[k][3] = 0.f;
+        }
+        P->big_ok = ok && covered == m;
+        if (!P->big_ok) su.n = 0;
     }
     P->xyz.swap(raw);
     std::lock_guard<std::mutex> lk(mu);
@@ -1354,10 +1492,10 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
 // copies a prepared template into the context's template arena at point offset `off` (a multiple of 64)
 static int upload_template(cd_context* c, int slot, int off, const PreparedTemplate& P) {
     const int nrun = P.m_pad / ICP_SUB;
-    HIPCHK(c, copy_sync(c, c->d_tpl + off, P.cell_pts.data(), sizeof(float4) * (size_t)P.m, hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->d_tpl + off, P.cell_pts.data(), sizeof(float4) * (size_t)P.m_pad, hipMemcpyHostToDevice));
     HIPCHK(c, copy_sync(c, c->d_tlo + off / ICP_SUB, P.cell_lo.data(), sizeof(float4) * (size_t)nrun, hipMemcpyHostToDevice));
     HIPCHK(c, copy_sync(c, c->d_thi + off / ICP_SUB, P.cell_hi.data(), sizeof(float4) * (size_t)nrun, hipMemcpyHostToDevice));
-    HIPCHK(c, copy_sync(c, c->d_tplk + off, P.kd_pts.data(), sizeof(float4) * (size_t)P.m, hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->d_tplk + off, P.kd_pts.data(), sizeof(float4) * (size_t)P.m_pad, hipMemcpyHostToDevice));
     HIPCHK(c, copy_sync(c, c->d_tlok + off / ICP_SUB, P.kd_lo.data(), sizeof(float4) * (size_t)nrun, hipMemcpyHostToDevice));
     HIPCHK(c, copy_sync(c, c->d_thik + off / ICP_SUB, P.kd_hi.data(), sizeof(float4) * (size_t)nrun, hipMemcpyHostToDevice));
     if (!P.kdmap.empty())
@@ -1370,6 +1508,8 @@ static int upload_template(cd_context* c, int slot, int off, const PreparedTempl
     c->tpl_off[slot] = off;
     c->tpl_m[slot] = P.m;
     c->tpl_gridded[slot] = grid.ncell > 0;
+    c->tpl_big[slot] = P.big_ok;
+    HIPCHK(c, copy_sync(c, c->d_super + slot, &P.super, sizeof(IcpSuper), hipMemcpyHostToDevice));
     return CD_OK;
 }
 
@@ -1406,7 +1546,7 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
     return CD_OK;
 }
 
-int cd_crop_voxel(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float* out_xyz,
+static int cd_crop_voxel_impl(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float* out_xyz,
                   uint32_t* out_rgb, int capacity, int* out_n_cropped, int* out_n_voxels) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1459,7 +1599,7 @@ static int load_as(cd_context* c, const void* xyz, size_t stride, int n, float4*
     return CD_OK;
 }
 
-int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, float coeff[4],
+static int cd_segment_plane_impl(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, float coeff[4],
                      int32_t* inliers, int capacity, int* out_n_inliers, int* out_iterations) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1494,7 +1634,7 @@ int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const
 // surface_normal_estimation.cpp:167-234.  The three constrained fits run on the device (cd_segment_plane's
 // stages); the bookkeeping between them (ExtractIndices, pcl::compute3DCentroid - a sequential float32 sum -,
 // the size sort, the handedness flip and the pose assembly) is the callback's own host code.
-int cd_surface_frame(cd_context* c, const void* xyz, size_t stride, int n, const float table_normal[3], int invert,
+static int cd_surface_frame_impl(cd_context* c, const void* xyz, size_t stride, int n, const float table_normal[3], int invert,
                      const cd_params* p, cd_surface_frame_result* out) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1567,7 +1707,7 @@ int cd_surface_frame(cd_context* c, const void* xyz, size_t stride, int n, const
     return CD_OK;
 }
 
-int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4],
+static int cd_bbox_filter_impl(cd_context* c, const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4],
                    int32_t* out_indices, int capacity, int* out_n) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1593,7 +1733,7 @@ int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const d
     return CD_OK;
 }
 
-int cd_extract(cd_context* c, const void* points, size_t stride, int n, const int32_t* indices, int n_indices, int negative,
+static int cd_extract_impl(cd_context* c, const void* points, size_t stride, int n, const int32_t* indices, int n_indices, int negative,
                void* out_points, int capacity, int* out_n) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1644,7 +1784,7 @@ int cd_extract(cd_context* c, const void* points, size_t stride, int n, const in
     return CD_OK;
 }
 
-int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels,
+static int cd_cluster_impl(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels,
                int32_t* sizes, int sizes_capacity, int* out_k) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1666,7 +1806,7 @@ int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_pa
     return CD_OK;
 }
 
-int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, const cd_params* p,
+static int cd_icp_impl(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, const cd_params* p,
            cd_cluster_result* out, float* aligned) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1693,14 +1833,14 @@ int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, c
     return c->h_st[0].status;
 }
 
-int cd_process_batch_device(cd_context* c, const void* d_frames, size_t stride, int points_per_frame, int n_frames,
+static int cd_process_batch_device_impl(cd_context* c, const void* d_frames, size_t stride, int points_per_frame, int n_frames,
                             const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
     return process_batch_impl(c, d_frames, stride, points_per_frame, n_frames, p, results, plane_inliers, labels);
 }
 
-int cd_process_batch(cd_context* c, const void* frames, size_t stride, int points_per_frame, int n_frames,
+static int cd_process_batch_impl(cd_context* c, const void* frames, size_t stride, int points_per_frame, int n_frames,
                      const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1800,7 +1940,7 @@ int cd_get_cluster_points(cd_context* c, int frame, int k, int aligned, void* ou
     return CD_OK;
 }
 
-int cd_ground_plane(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float coeff[4], void* out_records,
+static int cd_ground_plane_impl(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float coeff[4], void* out_records,
                     int capacity, int* out_n, int* out_n_inliers) {
     if (!c) return CD_ERR_INVALID_ARG;
     hipSetDevice(c->device);
@@ -1849,6 +1989,48 @@ int cd_set_frame_guesses(cd_context* c, const float* guesses, int n_frames) {
         if (!std::isfinite(guesses[i])) return fail(c, CD_ERR_INVALID_ARG, "a guess holds a non-finite value");
     c->frame_guess.assign(guesses, guesses + 16 * (size_t)n_frames);
     return CD_OK;
+}
+
+// the compute entry points proper: each call runs under the per-device scan lock (with_scan_retry)
+int cd_crop_voxel(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float* out_xyz, uint32_t* out_rgb, int capacity, int* out_n_cropped, int* out_n_voxels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_crop_voxel_impl(c, points, stride, n, p, out_xyz, out_rgb, capacity, out_n_cropped, out_n_voxels); });
+}
+int cd_segment_plane(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, float coeff[4], int32_t* inliers, int capacity, int* out_n_inliers, int* out_iterations) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_segment_plane_impl(c, xyz, stride, n, p, coeff, inliers, capacity, out_n_inliers, out_iterations); });
+}
+int cd_surface_frame(cd_context* c, const void* xyz, size_t stride, int n, const float table_normal[3], int invert, const cd_params* p, cd_surface_frame_result* out) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_surface_frame_impl(c, xyz, stride, n, table_normal, invert, p, out); });
+}
+int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const double P[12], const int32_t rect[4], int32_t* out_indices, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_bbox_filter_impl(c, xyz, stride, n, P, rect, out_indices, capacity, out_n); });
+}
+int cd_extract(cd_context* c, const void* points, size_t stride, int n, const int32_t* indices, int n_indices, int negative, void* out_points, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_extract_impl(c, points, stride, n, indices, n_indices, negative, out_points, capacity, out_n); });
+}
+int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels, int32_t* sizes, int sizes_capacity, int* out_k) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_cluster_impl(c, xyz, stride, n, p, labels, sizes, sizes_capacity, out_k); });
+}
+int cd_icp(cd_context* c, int slot, const void* src_xyz, size_t stride, int n, const cd_params* p, cd_cluster_result* out, float* aligned) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_icp_impl(c, slot, src_xyz, stride, n, p, out, aligned); });
+}
+int cd_process_batch_device(cd_context* c, const void* d_frames, size_t stride, int points_per_frame, int n_frames, const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_process_batch_device_impl(c, d_frames, stride, points_per_frame, n_frames, p, results, plane_inliers, labels); });
+}
+int cd_process_batch(cd_context* c, const void* frames, size_t stride, int points_per_frame, int n_frames, const cd_params* p, cd_frame_result* results, int32_t* plane_inliers, int32_t* labels) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_process_batch_impl(c, frames, stride, points_per_frame, n_frames, p, results, plane_inliers, labels); });
+}
+int cd_ground_plane(cd_context* c, const void* points, size_t stride, int n, const cd_params* p, float coeff[4], void* out_records, int capacity, int* out_n, int* out_n_inliers) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&]() { return cd_ground_plane_impl(c, points, stride, n, p, coeff, out_records, capacity, out_n, out_n_inliers); });
 }
 
 int cd_get_timing(const cd_context* c, cd_timing* out) {

@@ -352,11 +352,19 @@ __device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
 // shrinks to the cells of q_x -+ sqrt(rem).
 // The point loop has no divergent branch: a lane without a point to test reads the +inf pad point `pad`, whose key can never
 // win.  (A select-only version of the row step was measured too: same time, so the row step keeps its early-outs.)
+// SH = bits of the stored position in the low word of a key: 13 for an LDS-resident template (positions and original
+// indices < 2^13, "no index" = 0x7fffffff), 16 for a template read from global memory (both < 2^16, "no index" = all ones).
+template <int SH>
+struct KeyFmt {
+    static constexpr unsigned NONE = SH == 13 ? 0x7fffffffu : 0xffffffffu;
+    static constexpr unsigned POS_MASK = (1u << SH) - 1u;
+};
+template <int SH = 13>
 __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
                                             QueryRegs& q, int pad) {
     // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
     // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it)
-    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
+    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)KeyFmt<SH>::NONE;
     const float slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
     const float sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
     const float slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
@@ -412,20 +420,42 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
 #ifdef CD_STATS
             { const unsigned long long pb_ = ballot64(i < b); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[6], 1ull); atomicAdd(&g_icp_stats[7], (unsigned long long)__popcll(pb_)); } }
 #endif
+            if constexpr (SH == 16) {
+                // template in global memory: a trip costs an L2 round trip, so four points are in flight per trip
+                const int i0 = min(i, pad), i1 = min(i + 1, pad), i2 = min(i + 2, pad), i3 = min(i + 3, pad);
+                const float4 t = s_tpl[(unsigned)i0];
+                const float4 u = s_tpl[(unsigned)i1];
+                const float4 v = s_tpl[(unsigned)i2];
+                const float4 w = s_tpl[(unsigned)i3];
+                const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
+                const float f = dist2(q.px, q.py, q.pz, v.x, v.y, v.z);
+                const float h = dist2(q.px, q.py, q.pz, w.x, w.y, w.z);
+                const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0);
+                const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1);
+                const unsigned long long kf_ = ((unsigned long long)__float_as_uint(f) << 32) | (((unsigned)__float_as_int(v.w) << SH) | (unsigned)i2);
+                const unsigned long long kh_ = ((unsigned long long)__float_as_uint(h) << 32) | (((unsigned)__float_as_int(w.w) << SH) | (unsigned)i3);
+                lkey = kd_ < lkey ? kd_ : lkey;
+                lkey = ke_ < lkey ? ke_ : lkey;
+                lkey = kf_ < lkey ? kf_ : lkey;
+                lkey = kh_ < lkey ? kh_ : lkey;
+                i += 4;
+            } else {
             const int i0 = min(i, pad), i1 = min(i + 1, pad);
-            const float4 t = s_tpl[i0];
-            const float4 u = s_tpl[i1];
+            const float4 t = s_tpl[(unsigned)i0];   // (unsigned: a template in global memory is then addressed as base + 32-bit offset)
+            const float4 u = s_tpl[(unsigned)i1];
             const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
             const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
-            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << 13) | (unsigned)i0);
-            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << 13) | (unsigned)i1);
+            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0);
+            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1);
             lkey = kd_ < lkey ? kd_ : lkey;
             lkey = ke_ < lkey ? ke_ : lkey;
             i += 2;
+            }
         }
     }
     const unsigned lo = (unsigned)(lkey & 0xffffffffull);
-    if (act && lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
+    if (act && lo != KeyFmt<SH>::NONE) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & KeyFmt<SH>::POS_MASK); q.poi = (int)(lo >> SH); }
 }
 
 // Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
@@ -595,6 +625,82 @@ __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsign
     }
 }
 
+
+
+// ---------------------------------------------------------------------------------------
+// Wave-per-query search over a template that does NOT fit LDS (more than ICP_TPL_LDS points; up to 65535): the points stay in
+// global memory (a few hundred KiB: L2-resident) in k-d patch order, so a patch is ONE coalesced 1 KiB read; the patch boxes
+// (32 B each) are in LDS, and a second level above them - the boxes of k-d subtrees of at most 64 patches ("superpatches",
+// IcpSuper; lane l keeps superpatch l's box in registers) - tells with one ballot which runs of <= 64 patch boxes need
+// testing at all.  Same exactness argument as the run boxes: a box bound is a lower bound of the canonical float distance
+// to everything inside it, and a superpatch box contains its patch boxes.
+// ---------------------------------------------------------------------------------------
+struct SuperRegs { float4 L, H; int first, cnt; };   // lane l: box, first patch and patch count of superpatch l (+inf box: none)
+
+__device__ __forceinline__ void search_patches_big(const float4* __restrict__ tplk, const unsigned short* __restrict__ kdmap,
+                                                   const float4* s_plo, const float4* s_phi, const SuperRegs& sp, QueryRegs& q,
+                                                   unsigned long long todo, unsigned long long* slot) {
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int k = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+        const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+        const unsigned long long bound = ((unsigned long long)__float_as_uint(best) << 32) | 0xffffffffull;
+        unsigned long long lkey = bound;
+        unsigned long long ma = ballot64(box_lb(sp.L, sp.H, x, y, z) <= best);
+#ifdef CD_STATS
+        if (lane == 0) atomicAdd(&g_icp_stats[2], 1ull);
+#endif
+        while (ma) {
+            const int sidx = __ffsll((long long)ma) - 1;
+            ma &= ma - 1;
+            const int first = __builtin_amdgcn_readlane(sp.first, sidx), cnt = __builtin_amdgcn_readlane(sp.cnt, sidx);
+            const int pl = first + min(lane, cnt - 1);
+            unsigned long long mp = ballot64(lane < cnt && box_lb(s_plo[pl], s_phi[pl], x, y, z) <= best);
+#ifdef CD_STATS
+            if (lane == 0) atomicAdd(&g_icp_stats[1], (unsigned long long)__popcll(mp));
+#endif
+            while (mp) {   // two patches per trip: their loads are in flight together (an odd one out is read twice)
+                const int r0 = first + __ffsll((long long)mp) - 1;
+                mp &= mp - 1;
+                const int r1 = mp ? first + __ffsll((long long)mp) - 1 : r0;
+                mp &= mp - 1;
+                const float4 t = tplk[(unsigned)(r0 * ICP_SUB + lane)];
+                const float4 u = tplk[(unsigned)(r1 * ICP_SUB + lane)];
+                const unsigned pt = kdmap[(unsigned)(r0 * ICP_SUB + lane)];
+                const unsigned pu = kdmap[(unsigned)(r1 * ICP_SUB + lane)];
+                const float d = dist2(x, y, z, t.x, t.y, t.z);
+                const float e = dist2(x, y, z, u.x, u.y, u.z);
+                const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << 16) | pt);
+                const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << 16) | pu);
+                lkey = kd_ < lkey ? kd_ : lkey;
+                lkey = ke_ < lkey ? ke_ : lkey;
+            }
+        }
+        // minimum over the wave: as far_end (none / exactly one / several lanes beat the bound)
+        const unsigned long long imp = ballot64(lkey < bound);
+        if (imp == 0ull) continue;
+        unsigned long long res;
+        if ((imp & (imp - 1ull)) == 0ull) {
+            const int src = __ffsll((long long)imp) - 1;
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lkey >> 32), src);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)lkey, src);
+            res = ((unsigned long long)hi << 32) | lo;
+        } else {
+            if (lane == k) __hip_atomic_store(slot, bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            if (lkey < bound) __hip_atomic_fetch_min(slot, lkey, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            res = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        }
+        const bool mine = lane == k;
+        const unsigned lo = (unsigned)res;
+        q.pbest = mine ? __uint_as_float((unsigned)(res >> 32)) : q.pbest;
+        q.pbi = mine ? (int)(lo & 0xffffu) : q.pbi;
+        q.poi = mine ? (int)(lo >> 16) : q.poi;
+    }
+}
 
 __device__ __forceinline__ void store_queries(const QueryRegs& q, int nk, int* nn, float* d2buf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1381,21 +1487,30 @@ __device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, co
     }
 }
 
-__global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* __restrict__ order,
-                                                           const IcpCluster* __restrict__ cl, IcpState* st,
-                                                           unsigned long long* __restrict__ accf,
-                                                           const float4* __restrict__ tpl, const float4* __restrict__ tlo,
-                                                           const float4* __restrict__ thi,
-                                                           const unsigned short* __restrict__ kdmap,
-                                                           const IcpGrid* __restrict__ grids,
-                                                           const unsigned short* __restrict__ tcell, float4* src,
-                                                           const float4* __restrict__ src0, int* nn, int* queue,
-                                                           const int* __restrict__ wgtab, IcpParams prm) {
-    __shared__ float4 s_tpl[ICPT_IMG];
+// BIG = false: k_icp_pipe, the template (<= ICP_TPL_LDS points) and its k-d position table live in LDS.
+// BIG = true : k_icp_pipe_big, a template of up to 65535 points stays in global memory (L2-resident: a few hundred KiB read by
+//              every workgroup) - the grid walk reads the cell-sorted copy `tpl` point by point, the wave-per-query search the
+//              k-d ordered copy `tplk` patch by patch (search_patches_big); LDS holds the cell start table and the patch boxes.
+//              Same pipeline, same arithmetic, same tie rule: bit-identical results (keys carry 16-bit positions).
+template <bool BIG>
+__device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ order,
+                                              const IcpCluster* __restrict__ cl, IcpState* st,
+                                              unsigned long long* __restrict__ accf,
+                                              const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                              const float4* __restrict__ thi,
+                                              const unsigned short* __restrict__ kdmap,
+                                              const IcpGrid* __restrict__ grids,
+                                              const unsigned short* __restrict__ tcell, float4* src,
+                                              const float4* __restrict__ src0, int* nn, int* queue,
+                                              const int* __restrict__ wgtab, IcpParams prm,
+                                              const float4* __restrict__ tplk, const IcpSuper* __restrict__ supers) {
+    __shared__ float4 s_tpl[BIG ? 1 : ICPT_IMG];
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
-    __shared__ unsigned short s_kd[ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
+    __shared__ unsigned short s_kd[BIG ? 1 : ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
+    __shared__ float4 s_plo[BIG ? ICP_BIG_PATCHES : 1], s_phi[BIG ? ICP_BIG_PATCHES : 1];   // BIG: boxes of all k-d patches
+    constexpr int KSH = BIG ? 16 : 13;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // A workgroup keeps ONE (LDS-resident, gridded) template for its whole life.  With several templates in a launch
     // (every cluster against every template, opd flavour with template_slot = -1) the host groups the clusters by template,
@@ -1408,14 +1523,34 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
     const float4* tp = tpl + c0.tpl_off;
     const int tpl_m = c0.tpl_m;
     const float rmax = __fmul_rn(prm.grid_rc, g.cell);
-    const int gpad = (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB;   // first point of the +inf pad run of the staged image
+    // the point a lane without work reads: the first point of the +inf pad run of the staged image; from global memory the
+    // template's last point (testing a real template point is always harmless: it can only be the answer if it is the answer)
+    const int gpad = BIG ? tpl_m - 1 : (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB;
     RunBoxes bx;
+    SuperRegs sp;
+    const float4* tk = BIG ? tplk + c0.tpl_off : nullptr;
+    const unsigned short* km = kdmap + c0.tpl_off;
     for (int i = threadIdx.x; i <= g.ncell; i += ICPT_THREADS) s_cs[i] = tcell[g.cell_off + i];
-    for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = kdmap[c0.tpl_off + i];
-    stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
+    if constexpr (!BIG) {
+        for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = km[i];
+        stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
+    } else {
+        const int nruns = (tpl_m + ICP_SUB - 1) / ICP_SUB;
+        for (int i = threadIdx.x; i < nruns; i += ICPT_THREADS) { s_plo[i] = tlo[c0.tpl_off / ICP_SUB + i]; s_phi[i] = thi[c0.tpl_off / ICP_SUB + i]; }
+        const IcpSuper& su = supers[c0.slot];
+        const float inf = __uint_as_float(0x7f800000u);
+        sp.L = sp.H = make_float4(inf, inf, inf, 0.f);
+        sp.first = 0; sp.cnt = 1;
+        if (lane < su.n) {
+            sp.L = make_float4(su.lo[lane][0], su.lo[lane][1], su.lo[lane][2], 0.f);
+            sp.H = make_float4(su.hi[lane][0], su.hi[lane][1], su.hi[lane][2], 0.f);
+            sp.first = su.first[lane]; sp.cnt = su.cnt[lane];
+        }
+        __syncthreads();
+    }
     // lane l keeps the boxes of patch l of the LEFT half of the k-d root split and of patch l of the RIGHT half
     const int psplit = g.kd_split;
-    {
+    if constexpr (!BIG) {
         const int nruns = (tpl_m + ICP_SUB - 1) / ICP_SUB;
         const float inf = __uint_as_float(0x7f800000u);
         const float4 none = make_float4(inf, inf, inf, 0.f);
@@ -1486,18 +1621,21 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                             q.pbest = 3.402823466e38f;
                             if (it > 0) {
                                 q.pbi = nnq[myq];
-                                const float4 q0p = s_tpl[q.pbi];
+                                const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                                 q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z);
                             }
                             if (it < 3) {   // coarse seeds: first point of every run
                                 for (int j = 0; j < tpl_m; j += ICP_SUB) {
-                                    const float4 t = s_tpl[j];
+                                    const float4 t = BIG ? tp[j] : s_tpl[j];
                                     const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
                                     if (d < q.pbest) { q.pbest = d; q.pbi = j; }
                                 }
                             }
                             q.pbest = seed_bound(q.pbest);
-                            q.poi = __float_as_int(s_tpl[q.pbi].w);
+                            q.poi = __float_as_int((BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi]).w);
+#ifdef CD_STATS
+                            if (lane == 0) atomicAdd(&g_icp_stats[8], (unsigned long long)nk * (unsigned long long)((it > 0 ? 1 : 0) + (it < 3 ? (tpl_m + ICP_SUB - 1) / ICP_SUB : 0)));   // seed tests
+#endif
                         } else {            // final X <- T*X, then getFitnessScore() of Tfinal * original source
                             float ox, oy, oz;
                             xform(sl->so.T, p.x, p.y, p.z, ox, oy, oz);
@@ -1505,18 +1643,23 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                             const float4 p0 = pts0[myq];
                             xform(sl->so.Tfinal, p0.x, p0.y, p0.z, q.px, q.py, q.pz);
                             q.pbi = nnq[myq];
-                            const float4 q0p = s_tpl[q.pbi];
+                            const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                             q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z));
                             q.poi = __float_as_int(q0p.w);
                         }
                     }
+                    CD_PHASE(1)
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (ballot64(near)) grid_search(s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search<KSH>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
+                    CD_PHASE(2)
+                    if constexpr (BIG) {
+                        search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave]);
+                    } else {
                     // which halves of the template can hold a point within this lane's bound (all lanes at once)
                     const float4 hl0 = make_float4(g.half_lo[0][0], g.half_lo[0][1], g.half_lo[0][2], 0.f), hh0 = make_float4(g.half_hi[0][0], g.half_hi[0][1], g.half_hi[0][2], 0.f);
                     const float4 hl1 = make_float4(g.half_lo[1][0], g.half_lo[1][1], g.half_lo[1][2], 0.f), hh1 = make_float4(g.half_hi[1][0], g.half_hi[1][1], g.half_hi[1][2], 0.f);
@@ -1531,6 +1674,8 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
 #else
                     search_patches(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave]);
 #endif
+                    }
+                    CD_PHASE(4)
                     // The pass's 16 moment terms go into the slot's accumulators right away: no sum is carried in registers
                     // across the searches (32 VGPRs that the search loops would otherwise spill around).
                     unsigned long long S[16];
@@ -1539,7 +1684,7 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                     if (lane < nk) {
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
-                            const float4 qq = s_tpl[q.pbi];
+                            const float4 qq = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                             const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
 #pragma unroll
                             for (int a = 0; a < 3; ++a) {
@@ -1554,9 +1699,9 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
                         }
                     }
                     wave_fold_to_lds(S, phase == PH_ITER ? 16 : 1, sl->acc);
+                    CD_PHASE(5)
                 }
-                CD_PHASE(1)
-                CD_PHASE(2)
+                CD_PHASE(5)
             }
             __threadfence_block();
             int a = 0;
@@ -1595,6 +1740,32 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* _
         atomicAdd(&g_icp_stats[14], dt); atomicMax(&g_icp_stats[15], dt); atomicAdd(&g_icp_stats[7], 1ull);
     }
 #endif
+}
+
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe(int ncl, const int* __restrict__ order,
+                                                           const IcpCluster* __restrict__ cl, IcpState* st,
+                                                           unsigned long long* __restrict__ accf,
+                                                           const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                           const float4* __restrict__ thi,
+                                                           const unsigned short* __restrict__ kdmap,
+                                                           const IcpGrid* __restrict__ grids,
+                                                           const unsigned short* __restrict__ tcell, float4* src,
+                                                           const float4* __restrict__ src0, int* nn, int* queue,
+                                                           const int* __restrict__ wgtab, IcpParams prm) {
+    icp_pipe_body<false>(ncl, order, cl, st, accf, tpl, tlo, thi, kdmap, grids, tcell, src, src0, nn, queue, wgtab, prm, nullptr, nullptr);
+}
+__global__ void __launch_bounds__(ICPT_THREADS) k_icp_pipe_big(int ncl, const int* __restrict__ order,
+                                                               const IcpCluster* __restrict__ cl, IcpState* st,
+                                                               unsigned long long* __restrict__ accf,
+                                                               const float4* __restrict__ tpl, const float4* __restrict__ tlo,
+                                                               const float4* __restrict__ thi,
+                                                               const unsigned short* __restrict__ kdmap,
+                                                               const IcpGrid* __restrict__ grids,
+                                                               const unsigned short* __restrict__ tcell, float4* src,
+                                                               const float4* __restrict__ src0, int* nn, int* queue,
+                                                               const int* __restrict__ wgtab, IcpParams prm,
+                                                               const float4* __restrict__ tplk, const IcpSuper* __restrict__ supers) {
+    icp_pipe_body<true>(ncl, order, cl, st, accf, tpl, tlo, thi, kdmap, grids, tcell, src, src0, nn, queue, wgtab, prm, tplk, supers);
 }
 
 // getFitnessScore(): mean squared NN distance of T_final * (original source)
@@ -1723,6 +1894,15 @@ void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster*
     if (ncl <= 0 || n_wg <= 0) return;
     hipLaunchKernelGGL(k_icp_pipe, dim3(n_wg), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlo, thi,
                        kdmap, grids, tcell, src, src0, nn, queue, wgtab, prm);
+}
+
+void launch_icp_pipe_big(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
+                         const float4* tpl, const float4* tplk, const float4* tlok, const float4* thik, const unsigned short* kdmap,
+                         const IcpGrid* grids, const IcpSuper* supers, const unsigned short* tcell, float4* src, const float4* src0,
+                         int* nn, int* queue, int n_wg, const int* wgtab, IcpParams prm) {
+    if (ncl <= 0 || n_wg <= 0) return;
+    hipLaunchKernelGGL(k_icp_pipe_big, dim3(n_wg), dim3(ICPT_THREADS), 0, s, ncl, order, cl, st, accf, tpl, tlok, thik,
+                       kdmap, grids, tcell, src, src0, nn, queue, wgtab, prm, tplk, supers);
 }
 
 }  // namespace cd

@@ -73,6 +73,10 @@ void launch_icp_pipe(hipStream_t s, int ncl, const int* order, const IcpCluster*
                      const float4* tpl, const float4* tlo, const float4* thi, const unsigned short* kdmap, const IcpGrid* grids,
                      const unsigned short* tcell, float4* src, const float4* src0, int* nn,
                      int* queue, int n_wg, const int* wgtab, IcpParams prm);
+void launch_icp_pipe_big(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
+                         const float4* tpl, const float4* tplk, const float4* tlok, const float4* thik, const unsigned short* kdmap,
+                         const IcpGrid* grids, const IcpSuper* supers, const unsigned short* tcell, float4* src, const float4* src0,
+                         int* nn, int* queue, int n_wg, const int* wgtab, IcpParams prm);
 void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
                         const float4* tpl, const float4* tlo, const float4* thi, const IcpGrid* grids,
                         const unsigned short* tcell, float4* src, const float4* src0, int* nn,

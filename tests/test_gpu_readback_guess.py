@@ -235,3 +235,41 @@ def test_icp_guess_in_every_driver(O, template, frames4, monkeypatch, mode):
         c.set_frame_guesses(None)
     finally:
         c.close()
+
+
+def test_stalled_chained_scan_is_redone_alone(O, template, frames4, monkeypatch):
+    """A chained scan that reports a stall (forced here: CUBOID_FORCE_SCAN_STALL; on hardware only several contexts blocking
+    each other's ordered compactions could cause one) does not fail the call: it is redone with the device to itself, the
+    results are the usual ones and cd_timing says so.  Fused batch, cd_ground_plane, cd_crop_voxel and cd_extract."""
+    monkeypatch.setenv("CUBOID_FORCE_SCAN_STALL", "1")
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=2)
+    monkeypatch.delenv("CUBOID_FORCE_SCAN_STALL")
+    try:
+        c.set_template(0, template)
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        res, _, _ = c.process_batch(np.stack(frames4[:2], 0), prm)
+        assert c.timing().scan_retries == 1
+        for f in range(2):
+            o = O.process_frame(frames4[f], prm, template)["result"]
+            assert res[f].n_clusters == o.n_clusters
+            for k in range(o.n_clusters):
+                _same_cluster(res[f].clusters[k], o.clusters[k])
+        res, _, _ = c.process_batch(np.stack(frames4[:2], 0), prm)
+        assert c.timing().scan_retries == 0
+    finally:
+        c.close()
+    monkeypatch.setenv("CUBOID_FORCE_SCAN_STALL", "3")      # twice in a row: the call fails with a message, the context stays usable
+    c = capi.Context(max_points=synth.WIDTH * synth.HEIGHT, max_frames=1)
+    monkeypatch.delenv("CUBOID_FORCE_SCAN_STALL")
+    try:
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        with pytest.raises(capi.CuboidError) as e:
+            c.crop_voxel(frames4[0], prm)
+        assert e.value.status == capi.CD_ERR_DEVICE and "stalled twice" in str(e.value)
+        vox, rgb, nc = c.crop_voxel(frames4[0], prm, want_rgb=True)      # third forced stall, then a clean redo
+        st, vo, ro, nco, _ = O.crop_voxel(frames4[0], prm, want_rgb=True)
+        assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+    finally:
+        c.close()

@@ -125,8 +125,10 @@ def test_every_icp_driver_gives_the_same_bits(O, template, mode, monkeypatch):
 @pytest.mark.parametrize("mode", ["sliced", "cluster", "pipe"])
 def test_template_larger_than_lds_in_batch_mode(O, mode, which, monkeypatch):
     """A 10 700-point template - and the reference's own 21 400-point six-face template_cuboid_L200_W100_H75.pcd - do not
-    fit the LDS image: the whole-cluster drivers fall back to the chunked search of k_icp_cluster ('pipe' must notice
-    and do the same); results still match the oracle bit for bit."""
+    fit the LDS image: 'pipe' runs them through k_icp_pipe_big (the pipelined kernel with the template left in global
+    memory: grid walk over the cell-sorted copy, patch search over the k-d ordered one, two box levels), 'cluster' through
+    the chunked search of k_icp_cluster, 'sliced' through the chunked multi-launch driver; results match the oracle bit for
+    bit in all three."""
     from conftest import GOLDEN
     from perception_amd import pcd
     monkeypatch.setenv("CUBOID_ICP_MODE", mode)
@@ -267,12 +269,17 @@ def test_template_arena_is_reclaimed(O, template):
 
 
 @pytest.mark.gpu
-def test_config5_one_million_points_five_templates(O):
+@pytest.mark.parametrize("mode", ["auto", "pipe"])
+def test_config5_one_million_points_five_templates(O, mode, monkeypatch):
     """BASELINE config 5 as SURVEY 8(d) writes it: a 1 M-point frame (1000 x 1000 virtual sensor), five cuboids of distinct
     dimensions, five templates - the three the reference ships dims for (one of them the committed 1700-point file with its
     origin at a corner), 150x150x50 (9375 points: does NOT fit the LDS image) and 100x100x100 at d = 0.002 - crops widened
-    to the table, template_slot = -1: every cluster against every template, the lowest fitness wins."""
+    to the table, template_slot = -1: every cluster against every template, the lowest fitness wins.  mode 'pipe' forces
+    what a batch of such frames takes by itself: ONE ICP stage of two persistent launches side by side - k_icp_pipe for the
+    four template groups that fit LDS, k_icp_pipe_big for the 9375-point one."""
     from conftest import GOLDEN
+    if mode == "pipe":
+        monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
     from perception_amd import pcd
     frame = synth.frame_config5(0)
     assert frame.shape == (1000000, 4)
