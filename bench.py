@@ -235,14 +235,17 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, gather their rank ids and rank 0 "
                          "prints them (tests/test_bench_launcher.py)")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
-                         "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial)")
+                         "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial; "
+                         "default 5, config 5: 6 - measured, DESIGN.md section 6)")
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 256 if args.config == 3 else 8
     if args.steps is None:
         args.steps = 300 if args.config == 3 else 40
+    if args.inflight is None:
+        args.inflight = 5 if args.config == 3 else 6
     if args.steps < 1 or args.warmup < 0 or args.frames < 1:
         raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 

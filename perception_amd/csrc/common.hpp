@@ -26,7 +26,11 @@ constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses 
 constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
 constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
 constexpr int ICP_SUB = 64;                // template run length that carries one pruning box
+#if defined(CD_PIPE_SLOTS) && CD_PIPE_SLOTS > 2
+constexpr int ICP_TPL_LDS = 7552;          // (experiment builds with a third pipeline slot: one run less, the slot needs its LDS)
+#else
 constexpr int ICP_TPL_LDS = 7616;          // template points resident in LDS (119 runs, 119 KiB)
+#endif
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS

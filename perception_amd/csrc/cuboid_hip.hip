@@ -72,7 +72,7 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 1;                                              // clusters per workgroup a persistent ICP launch is sized for (CUBOID_ICP_CPW): 2 fills both pipeline slots
-    int icp_big_weight = 2;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT)
+    int icp_big_weight = 4;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; measured on config 5)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     std::shared_ptr<const struct PreparedTemplate> tpl_prep[CD_MAX_TEMPLATES];   // host copies (shared across contexts)

@@ -359,7 +359,9 @@ struct KeyFmt {
     static constexpr unsigned NONE = SH == 13 ? 0x7fffffffu : 0xffffffffu;
     static constexpr unsigned POS_MASK = (1u << SH) - 1u;
 };
-template <int SH = 13>
+// PK: the template image's .w already holds the key's low word (original index << SH | stored position): k_icp_pipe re-labels
+// its LDS image that way once, which takes one vector instruction per tested point out of both searches
+template <int SH = 13, bool PK = false>
 __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
                                             QueryRegs& q, int pad) {
     // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
@@ -446,8 +448,8 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
             const float4 u = s_tpl[(unsigned)i1];
             const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
             const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
-            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0);
-            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1);
+            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.w) : (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0));
+            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (PK ? (unsigned)__float_as_int(u.w) : (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1));
             lkey = kd_ < lkey ? kd_ : lkey;
             lkey = ke_ < lkey ? ke_ : lkey;
             i += 2;
@@ -563,13 +565,14 @@ __device__ __forceinline__ int far_next_patch(FarQ& f, int psplit) {   // wave-u
     else { r = psplit + __ffsll((long long)f.m1) - 1; f.m1 &= f.m1 - 1; }
     return r;
 }
+template <bool PK = false>
 __device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
     // lexicographic (d2, original index) minimum, rule C5, as ONE unsigned 64-bit compare: squared distances are non-negative
     // floats (or +inf / NaN-free here), which order like their bit patterns; no branch, no tie special case
     // The low word carries the stored position below the original index (both < 2^13 for an LDS-resident template; the
     // position is a function of the index, so the order is still (d2, original index)): the key alone is the whole answer.
     const float d = dist2(f.x, f.y, f.z, t.x, t.y, t.z);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t.w) << 13) | (unsigned)pos);
+    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.w) : (((unsigned)__float_as_int(t.w) << 13) | (unsigned)pos));
     f.lkey = key < f.lkey ? key : f.lkey;
 }
 // Minimum over the wave WITHOUT a reduction: the query's owner lane puts the bound key into the wave's LDS word, every lane
@@ -602,6 +605,7 @@ __device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsi
     q.pbi = mine ? (int)(lo & 0x1fffu) : q.pbi;
     q.poi = mine ? (int)(lo >> 13) : q.poi;
 }
+template <bool PK = false>
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
                                                unsigned long long todo, int psplit, int need, unsigned long long* slot, int* stat_acc = nullptr) {
     const int lane = threadIdx.x & 63;
@@ -619,7 +623,7 @@ __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsign
         while (A.m0 | A.m1) {
             const int r = far_next_patch(A, psplit);
             const int pos = s_kd[r * ICP_SUB + lane];
-            far_take(A, s_tpl[pos], pos);
+            far_take<PK>(A, s_tpl[pos], pos);
         }
         far_end(A, q, k, slot);
     }
@@ -1428,7 +1432,11 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
 // Arithmetic is that of k_icp_cluster / k_icp_iter + k_icp_solve + k_icp_fitness (order-free
 // integer moment sums), so results are bit-identical.
 // ---------------------------------------------------------------------------------------
-constexpr int PIPE_SLOTS = 2;
+#ifndef CD_PIPE_SLOTS
+#define CD_PIPE_SLOTS 2
+#endif
+constexpr int PIPE_SLOTS = CD_PIPE_SLOTS;   // clusters in flight per workgroup (2 ships; 3 was measured: DESIGN.md section 6)
+static_assert(PIPE_SLOTS >= 1 && PIPE_SLOTS <= 4, "one byte of the packed per-wave step counters per slot");
 enum { PH_ITER = 0, PH_FIT = 1, PH_EXHAUSTED = 2, PH_FILL = 3 };
 
 struct PipeSlot {
@@ -1534,6 +1542,13 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     if constexpr (!BIG) {
         for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = km[i];
         stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
+        // re-label the image: .w = the low word of a search key, (original index << 13) | position (pads: all ones, and +inf
+        // coordinates anyway); nothing in this kernel needs the bare original index
+        for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB + ICP_SUB; i += ICPT_THREADS) {
+            const unsigned oi = (unsigned)__float_as_int(s_tpl[i].w);
+            s_tpl[i].w = __uint_as_float(i < tpl_m ? ((oi << 13) | (unsigned)i) : 0xffffffffu);
+        }
+        __syncthreads();
     } else {
         const int nruns = (tpl_m + ICP_SUB - 1) / ICP_SUB;
         for (int i = threadIdx.x; i < nruns; i += ICPT_THREADS) { s_plo[i] = tlo[c0.tpl_off / ICP_SUB + i]; s_phi[i] = thi[c0.tpl_off / ICP_SUB + i]; }
@@ -1574,18 +1589,19 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
     const long long wg_t0 = wall_clock64();
 #endif
-    int my_epoch0 = 0, my_epoch1 = 0;
-    bool live0 = true, live1 = true;
-    while (live0 || live1) {
+    // per wave: the steps it has completed on each slot (one byte per slot, mod 256: waves are never a whole step apart) and
+    // the slots that still have work
+    unsigned my_ep = 0u, live = (1u << PIPE_SLOTS) - 1u;
+    while (live) {
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
-            if (!(sidx ? live1 : live0)) continue;
+            if (!((live >> sidx) & 1u)) continue;
             PipeSlot* sl = &s_slot[sidx];
-            const int want = sidx ? my_epoch1 : my_epoch0;
+            const int want = (int)((my_ep >> (8 * sidx)) & 0xffu);
             while (__hip_atomic_load(&sl->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != want) __builtin_amdgcn_s_sleep(2);
             __threadfence_block();
             CD_PHASE(0)
             const int phase = sl->phase;
-            if (phase == PH_EXHAUSTED) { if (sidx) live1 = false; else live0 = false; continue; }
+            if (phase == PH_EXHAUSTED) { live &= ~(1u << sidx); continue; }
             if (phase == PH_ITER || phase == PH_FIT) {
                 const int it = sl->it, n = sl->n;
                 float4* pts = src + sl->src_off;
@@ -1632,7 +1648,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                                 }
                             }
                             q.pbest = seed_bound(q.pbest);
-                            q.poi = __float_as_int((BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi]).w);
+                            q.poi = 0;   // (only the chunked searches of the other kernels carry the seed's original index)
 #ifdef CD_STATS
                             if (lane == 0) atomicAdd(&g_icp_stats[8], (unsigned long long)nk * (unsigned long long)((it > 0 ? 1 : 0) + (it < 3 ? (tpl_m + ICP_SUB - 1) / ICP_SUB : 0)));   // seed tests
 #endif
@@ -1652,7 +1668,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if (ballot64(near)) grid_search<KSH>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search<KSH, !BIG>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
 #endif
@@ -1666,13 +1682,13 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
+                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-                    search_patches(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave]);
+                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave]);
 #endif
                     }
                     CD_PHASE(4)
@@ -1727,10 +1743,10 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     sl->next_pass = 0;
                 }
                 __threadfence_block();
-                if (lane == 0) __hip_atomic_store(&sl->epoch, want + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_store(&sl->epoch, (want + 1) & 0xff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 CD_PHASE(3)
             }
-            if (sidx) ++my_epoch1; else ++my_epoch0;
+            my_ep = (my_ep & ~(0xffu << (8 * sidx))) | ((unsigned)((want + 1) & 0xff) << (8 * sidx));
         }
     }
 #ifdef CD_TIMERS
