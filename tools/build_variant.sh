@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../perception_amd/csrc"
 name=$1; src=$2; shift 2
 mkdir -p build/var ../lib/variants
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-value -Wno-unused-result"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -mllvm -amdgpu-atomic-optimizer-strategy=None -Wno-unused-value -Wno-unused-result"
 /opt/rocm/bin/hipcc $FLAGS "$@" -c $src -o build/var/$name.o
 objs=""
 for o in build/*.o; do
