@@ -443,13 +443,19 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
                 lkey = kh_ < lkey ? kh_ : lkey;
                 i += 4;
             } else {
-            const int i0 = min(i, pad), i1 = min(i + 1, pad);
-            const float4 t = s_tpl[(unsigned)i0];   // (unsigned: a template in global memory is then addressed as base + 32-bit offset)
+            // two points per trip, (i, i + 1), clamped together: one address, the second point 16 bytes on
+            const int i0 = min(i, pad - 1), i1 = i0 + 1;
+            const float4 t = s_tpl[(unsigned)i0];
             const float4 u = s_tpl[(unsigned)i1];
-            const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
-            const float e = dist2(q.px, q.py, q.pz, u.x, u.y, u.z);
-            const unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.w) : (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0));
-            const unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (PK ? (unsigned)__float_as_int(u.w) : (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1));
+            // (PK images are stored (x, y, key word, z))
+            const float d = dist2(q.px, q.py, q.pz, t.x, t.y, PK ? t.w : t.z);
+            const float e = dist2(q.px, q.py, q.pz, u.x, u.y, PK ? u.w : u.z);
+            unsigned long long kd_ = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.z) : (((unsigned)__float_as_int(t.w) << SH) | (unsigned)i0));
+            unsigned long long ke_ = ((unsigned long long)__float_as_uint(e) << 32) | (PK ? (unsigned)__float_as_int(u.z) : (((unsigned)__float_as_int(u.w) << SH) | (unsigned)i1));
+            // (opaque to the optimiser: compare AND select then use the key's own register pair, so the distance is formed in
+            // its high half instead of being copied there)
+            asm("" : "+v"(kd_));
+            asm("" : "+v"(ke_));
             lkey = kd_ < lkey ? kd_ : lkey;
             lkey = ke_ < lkey ? ke_ : lkey;
             i += 2;
@@ -571,8 +577,9 @@ __device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
     // floats (or +inf / NaN-free here), which order like their bit patterns; no branch, no tie special case
     // The low word carries the stored position below the original index (both < 2^13 for an LDS-resident template; the
     // position is a function of the index, so the order is still (d2, original index)): the key alone is the whole answer.
-    const float d = dist2(f.x, f.y, f.z, t.x, t.y, t.z);
-    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.w) : (((unsigned)__float_as_int(t.w) << 13) | (unsigned)pos));
+    const float d = dist2(f.x, f.y, f.z, t.x, t.y, PK ? t.w : t.z);   // (PK images are stored (x, y, key word, z))
+    unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (PK ? (unsigned)__float_as_int(t.z) : (((unsigned)__float_as_int(t.w) << 13) | (unsigned)pos));
+    asm("" : "+v"(key));   // (as in grid_search: keeps the key in the loaded quad's own registers)
     f.lkey = key < f.lkey ? key : f.lkey;
 }
 // Minimum over the wave WITHOUT a reduction: the query's owner lane puts the bound key into the wave's LDS word, every lane
@@ -1542,11 +1549,14 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     if constexpr (!BIG) {
         for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB; i += ICPT_THREADS) s_kd[i] = km[i];
         stage_chunk(tp, tlo + c0.tpl_off / ICP_SUB, thi + c0.tpl_off / ICP_SUB, 0, tpl_m, s_tpl, bx);
-        // re-label the image: .w = the low word of a search key, (original index << 13) | position (pads: all ones, and +inf
-        // coordinates anyway); nothing in this kernel needs the bare original index
+        // re-label the image: the low word of a search key, (original index << 13) | position (pads: all ones, and +inf
+        // coordinates anyway), replaces the bare original index, which nothing in this kernel needs ...
         for (int i = threadIdx.x; i < (tpl_m + ICP_SUB - 1) / ICP_SUB * ICP_SUB + ICP_SUB; i += ICPT_THREADS) {
-            const unsigned oi = (unsigned)__float_as_int(s_tpl[i].w);
-            s_tpl[i].w = __uint_as_float(i < tpl_m ? ((oi << 13) | (unsigned)i) : 0xffffffffu);
+            // ... and stored as (x, y, key word, z): the key word then sits in the even register of the loaded quad and the
+            // squared distance can be formed in the z register next to it - the 64-bit key (rule C5's compare) needs no move
+            const float4 p = s_tpl[i];
+            const unsigned oi = (unsigned)__float_as_int(p.w);
+            s_tpl[i] = make_float4(p.x, p.y, __uint_as_float(i < tpl_m ? ((oi << 13) | (unsigned)i) : 0xffffffffu), p.z);
         }
         __syncthreads();
     } else {
@@ -1638,12 +1648,12 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                             if (it > 0) {
                                 q.pbi = nnq[myq];
                                 const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
-                                q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z);
+                                q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, BIG ? q0p.z : q0p.w);
                             }
                             if (it < 3) {   // coarse seeds: first point of every run
                                 for (int j = 0; j < tpl_m; j += ICP_SUB) {
                                     const float4 t = BIG ? tp[j] : s_tpl[j];
-                                    const float d = dist2(q.px, q.py, q.pz, t.x, t.y, t.z);
+                                    const float d = dist2(q.px, q.py, q.pz, t.x, t.y, BIG ? t.z : t.w);
                                     if (d < q.pbest) { q.pbest = d; q.pbi = j; }
                                 }
                             }
@@ -1660,7 +1670,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                             xform(sl->so.Tfinal, p0.x, p0.y, p0.z, q.px, q.py, q.pz);
                             q.pbi = nnq[myq];
                             const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
-                            q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, q0p.z));
+                            q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, BIG ? q0p.z : q0p.w));
                             q.poi = __float_as_int(q0p.w);
                         }
                     }
@@ -1701,7 +1711,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
                             const float4 qq = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
-                            const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, qq.z};
+                            const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, BIG ? qq.z : qq.w};
 #pragma unroll
                             for (int a = 0; a < 3; ++a) {
                                 S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
