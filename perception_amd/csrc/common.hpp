@@ -169,6 +169,15 @@ __device__ __forceinline__ long long fixq(float v, int shift) {
     // float->double exact, power-of-two scale exact, round to nearest even (C4)
     return __double2ll_rn(ldexp((double)v, shift));
 }
+// The same integer for |v| * 2^shift < 2^50, without the double -> int64 conversion (five float64 instructions): adding
+// 1.5 * 2^52 to t = v * 2^shift rounds t to an integer (nearest, ties to even - the rounding of the addition itself) and
+// leaves rint(t) + 2^51 in the sum's 52 mantissa bits; their low 51 bits are rint(t) in two's complement.
+__device__ __forceinline__ unsigned long long fixq_fast(float v, int shift) {
+    const double u = __dadd_rn(ldexp((double)v, shift), 6755399441055744.0);
+    const unsigned long long b = (unsigned long long)__double_as_longlong(u);
+    const int hi = __builtin_amdgcn_sbfe((int)(unsigned)(b >> 32), 0, 19);   // sign-extend bit 50 (bit 18 of the high word): v_bfe_i32
+    return ((unsigned long long)(unsigned)hi << 32) | (unsigned)b;
+}
 // Adds the wave's per-lane 64-bit sums S[0..nsum) into dst[0..nsum) (LDS): an inclusive scan inside each row of 16 lanes - four
 // steps of a 64-bit add whose first operand comes from the lane 1, 2, 4, 8 to the left through the DPP path
 // (v_add_co_u32_dpp + v_addc_co_u32_dpp: no separate move, no LDS crossbar) - leaves the row totals in lanes 15, 31, 47, 63,

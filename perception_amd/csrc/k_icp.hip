@@ -1707,21 +1707,38 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     unsigned long long S[16];
 #pragma unroll
                     for (int i = 0; i < 16; ++i) S[i] = 0ull;
+                    // float -> fixed point (rule C4) in four instructions per term instead of eight (fixq_fast, common.hpp), valid
+                    // while every term stays below 2^50 / 2^shift; a wave with a lane outside that range (coordinates beyond 256 m,
+                    // neighbours more than 128 m away) takes the general conversion - same integers either way
+                    float4 qq = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (lane < nk && phase == PH_ITER) qq = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
+                    const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, BIG ? qq.z : qq.w};
+                    const float big_c = fmaxf(fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fabsf(pv[2])), fmaxf(fmaxf(fabsf(qv[0]), fabsf(qv[1])), fabsf(qv[2])));
+                    const bool fast = ballot64(lane < nk && !(big_c < 256.f && q.pbest < 16384.f)) == 0ull;
                     if (lane < nk) {
                         if (phase == PH_ITER) {
                             nnq[myq] = q.pbi;
-                            const float4 qq = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
-                            const float pv[3] = {q.px, q.py, q.pz}, qv[3] = {qq.x, qq.y, BIG ? qq.z : qq.w};
+                            if (fast) {
 #pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
-                                S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
+                                for (int a = 0; a < 3; ++a) {
+                                    S[a] = fixq_fast(pv[a], FIX_SHIFT);
+                                    S[3 + a] = fixq_fast(qv[a], FIX_SHIFT);
 #pragma unroll
-                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                                    for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = fixq_fast(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                                }
+                                S[15] = fixq_fast(q.pbest, FIX_SHIFT_D2);
+                            } else {
+#pragma unroll
+                                for (int a = 0; a < 3; ++a) {
+                                    S[a] = (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                                    S[3 + a] = (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                                    for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] = (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                                }
+                                S[15] = (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                             }
-                            S[15] = (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                         } else {
-                            S[0] = (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
+                            S[0] = fast ? fixq_fast(q.pbest, FIX_SHIFT_D2) : (unsigned long long)fixq(q.pbest, FIX_SHIFT_D2);
                         }
                     }
                     wave_fold_to_lds(S, phase == PH_ITER ? 16 : 1, sl->acc);
