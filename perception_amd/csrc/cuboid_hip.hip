@@ -316,6 +316,7 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     const int npass = (max_bits + RADIX_BITS - 1) / RADIX_BITS;
     int cur = 0;
     LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp));
+    if (cur < 0) return fail(c, CD_ERR_DEVICE, "radix sort: the scan state could not be zeroed");
     const uint32_t* vin = c->d_val[cur];   // zero passes (empty frames only): the permutation is never read
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)

@@ -218,12 +218,13 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
 // All passes of one sort.  Tact = sort tiles that hold data (max over the frames).  ghist [F][SORT_MAX_PASSES][RADIX] and
 // state [npass][F][Tact][RADIX] are zeroed here.  kp.enabled: key[0] holds the
 // absolute coordinate fields of k_crop_fused; the first pass writes voxel indices.  Returns the index of the buffers
-// that hold the sorted keys / the permutation.
+// that hold the sorted keys / the permutation, or -1 when the scan state could not be zeroed.
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
                       FrameState* fs, uint32_t* ghist, int* state, KeyPack kp) {
     if (npass <= 0) return 0;
-    (void)hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s);
-    (void)hipMemsetAsync(state, 0, sizeof(int) * (size_t)npass * F * Tact * RADIX, s);
+    // (a failure is also left in hipGetLastError, which the caller's LAUNCH() reads; -1 makes it explicit)
+    if (hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(state, 0, sizeof(int) * (size_t)npass * F * Tact * RADIX, s) != hipSuccess) return -1;
     const int G = (Tact + GHIST_TILES - 1) / GHIST_TILES;
     hipLaunchKernelGGL(k_radix_ghist, dim3(G, F), dim3(SORT_BLOCK), 0, s, key[0], N, npass, fs, ghist, kp);
     int cur = 0;
