@@ -80,8 +80,12 @@ struct cd_context {
     bool tpl_gridded[CD_MAX_TEMPLATES] = {false};                // slot has a cell start table
     bool tpl_big[CD_MAX_TEMPLATES] = {false};                    // slot does not fit LDS but has what k_icp_pipe_big needs (cell table, k-d map, superpatches)
     IcpSuper* d_super = nullptr;                                  // per template slot
-    hipStream_t stream2 = nullptr;                                // the second persistent ICP launch of a mixed-template batch runs beside the first
-    hipEvent_t ev2[2] = {nullptr, nullptr};
+    hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
+                                                                  // first (stream2); with icp_lowprio both are low-priority streams, so that CUs that come free go to the
+                                                                  // short front-end kernels of the other batches in flight before the next persistent workgroup
+    int icp_lowprio = 1;                                          // CUBOID_ICP_LOWPRIO: 0 never, 1 the launches of a mixed-template batch (measured: config 5 +30 %), 2 every
+                                                                  // persistent ICP launch (config 3: -1 %)
+    hipEvent_t ev2[3] = {nullptr, nullptr, nullptr};
     // ICP
     IcpCluster *d_cl = nullptr, *h_cl = nullptr;
     IcpWork *d_work = nullptr, *h_work = nullptr, *d_work2 = nullptr, *h_work2 = nullptr;
@@ -622,19 +626,26 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
-        const bool side = wg_of[1] > 0 && wg_of[2] > 0;
-        if (side) {   // everything uploaded so far is visible to the second stream
+        // the LDS-template launch goes to the context's stream (stream3 with icp_lowprio), the global-template launch beside it
+        hipStream_t s1 = c->icp_lowprio ? c->stream3 : c->stream;
+        hipStream_t s2 = (c->icp_lowprio || (wg_of[1] > 0 && wg_of[2] > 0)) ? c->stream2 : c->stream;
+        if (s1 != c->stream || s2 != c->stream) {   // everything uploaded so far is visible to the side streams
             HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev2[0], 0));
+            if (s1 != c->stream) HIPCHK(c, hipStreamWaitEvent(s1, c->ev2[0], 0));
+            if (s2 != c->stream) HIPCHK(c, hipStreamWaitEvent(s2, c->ev2[0], 0));
         }
         if (wg_of[1] > 0)
-            LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+            LAUNCH(c, launch_icp_pipe(s1, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                             c->d_queue, wg_of[1], c->d_wgtab + tab_of[1], ip));
         if (wg_of[2] > 0)
-            LAUNCH(c, launch_icp_pipe_big(side ? c->stream2 : c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid,
+            LAUNCH(c, launch_icp_pipe_big(s2, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid,
                                 c->d_super, c->d_tcell, c->d_src, c->d_src0, c->d_nn, c->d_queue, wg_of[2], c->d_wgtab + tab_of[2], ip));
-        if (side) {
-            HIPCHK(c, hipEventRecord(c->ev2[1], c->stream2));
+        if (s1 != c->stream && wg_of[1] > 0) {
+            HIPCHK(c, hipEventRecord(c->ev2[2], s1));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[2], 0));
+        }
+        if (s2 != c->stream && wg_of[2] > 0) {
+            HIPCHK(c, hipEventRecord(c->ev2[1], s2));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[1], 0));
         }
         c->timing.icp_kernel_launches = 1;
@@ -662,15 +673,24 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
+        hipStream_t si = c->icp_lowprio >= 2 ? c->stream3 : c->stream;
+        if (si != c->stream) {
+            HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(si, c->ev2[0], 0));
+        }
         if (pipe_ok)
-            LAUNCH(c, launch_icp_pipe(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+            LAUNCH(c, launch_icp_pipe(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                             c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
         else if (big_ok)
-            LAUNCH(c, launch_icp_pipe_big(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_super, c->d_tcell,
+            LAUNCH(c, launch_icp_pipe_big(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_super, c->d_tcell,
                                 c->d_src, c->d_src0, c->d_nn, c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
         else
-            LAUNCH(c, launch_icp_cluster(c->stream, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
+            LAUNCH(c, launch_icp_cluster(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                                c->d_queue, wg_cap, ip));
+        if (si != c->stream) {
+            HIPCHK(c, hipEventRecord(c->ev2[2], si));
+            HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[2], 0));
+        }
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         c->timing.icp_kernel_launches = 1;
         HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
@@ -1153,6 +1173,7 @@ void cd_destroy(cd_context* c) {
     if (c->d_guess) hipFree(c->d_guess);
     if (c->d_super) hipFree(c->d_super);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     for (auto& e : c->ev2) if (e) hipEventDestroy(e);
     void* host[] = {c->h_fs, c->h_valid, c->h_counts, c->h_active, c->h_model, c->h_models, c->h_have, c->h_sums, c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf, c->h_wgtab, c->h_ctl};
     for (void* p : host) if (p) hipHostFree(p);
@@ -1175,7 +1196,10 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->T = (max_points + TILE - 1) / TILE;
     const size_t N = (size_t)c->N, F = (size_t)c->F, T = (size_t)c->T, FN = F * N;
     // non-blocking: no implicit ordering against the NULL stream (torch ops, other contexts in flight)
-    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+    if (const char* m = std::getenv("CUBOID_ICP_LOWPRIO")) c->icp_lowprio = std::atoi(m);
+    int prio_least = 0, prio_greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess) prio_least = prio_greatest = 0;
+    bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, 0) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && dalloc(&c->d_fs, F) == hipSuccess && halloc(&c->h_fs, F) == hipSuccess;
     ok = ok && dalloc(&c->d_tileA, F * T) == hipSuccess && dalloc(&c->d_tileB, F * T) == hipSuccess && dalloc(&c->d_tileK, F * KICP * T) == hipSuccess;
@@ -1197,7 +1221,11 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_super, (size_t)CD_MAX_TEMPLATES) == hipSuccess;
-    ok = ok && hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) == hipSuccess;
+    {
+        const int prio = c->icp_lowprio ? prio_least : 0;
+        ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) == hipSuccess;
+        ok = ok && hipStreamCreateWithPriority(&c->stream3, hipStreamNonBlocking, prio) == hipSuccess;
+    }
     for (auto& e : c->ev2) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
     ok = ok && dalloc(&c->d_grid, (size_t)CD_MAX_TEMPLATES) == hipSuccess && dalloc(&c->d_tcell, (size_t)CD_MAX_TEMPLATES * ICP_CELL_STRIDE) == hipSuccess;
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
