@@ -220,10 +220,13 @@ __device__ int g_icp_cur_it;   // iteration bucket of the pass a wave is in (app
 __device__ __forceinline__ float next_up_nonneg(float d) { return __uint_as_float(__float_as_uint(d) + 1u); }
 __device__ __forceinline__ float seed_bound(float d0) { return d0 < 3.0e38f ? next_up_nonneg(d0) : __uint_as_float(0x7f800000u); }
 
+// (e_a = max(lo_a - q_a, q_a - hi_a, 0) is |q_a - clamp(q_a, lo_a, hi_a)|: one v_med3_f32 and one subtraction per axis instead of
+// two subtractions and a v_max3 - the squares are the same floats, the sign is gone after squaring.  An inverted (empty) box
+// gives 0 instead of "never": it is not pruned, which costs a test and no correctness.)
 __device__ __forceinline__ float box_lb(const float4& L, const float4& H, float x, float y, float z) {
-    const float ex = fmaxf(fmaxf(L.x - x, x - H.x), 0.f);
-    const float ey = fmaxf(fmaxf(L.y - y, y - H.y), 0.f);
-    const float ez = fmaxf(fmaxf(L.z - z, z - H.z), 0.f);
+    const float ex = __fsub_rn(x, __builtin_amdgcn_fmed3f(x, L.x, H.x));
+    const float ey = __fsub_rn(y, __builtin_amdgcn_fmed3f(y, L.y, H.y));
+    const float ez = __fsub_rn(z, __builtin_amdgcn_fmed3f(z, L.z, H.z));
     return __fadd_rn(__fadd_rn(__fmul_rn(ex, ex), __fmul_rn(ey, ey)), __fmul_rn(ez, ez));
 }
 
