@@ -40,3 +40,61 @@ def test_two_ranks_nccl_gather():
     assert out["verified"] is True
     assert out["icp"]["frames"] == 48          # every rank's records arrived, in frame order
     assert "cpu_baseline" not in out           # N = 1 only
+
+
+def _rank_on_gpu0(rank, world, port, q):
+    """one rank of the sharded path: HIP compute on GPU 0, its contiguous slice of the batch, record gather over gloo"""
+    import numpy as np
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch  # noqa: F401  (before libcuboid_hip.so: see conftest)
+    import torch.distributed as dist
+    from perception_amd import batch, capi, synth, templates
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    NF = 7                                                      # odd: ragged shards
+    frames = np.stack([synth.frame(i) for i in range(NF)], 0)
+    lo, hi = batch.shard_range(NF, rank, world)
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=max(hi - lo, 1))
+    ctx.set_template(0, templates.template_xyz32(**templates.DEFAULT_TEMPLATE))
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    runner = batch.ShardedBatchRunner(lambda fr: ctx.process_batch(fr, prm)[0], dist=dist)
+    rec = runner.run(frames[lo:hi], NF)
+    q.put((rank, rec.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_two_ranks_share_one_gpu_gather_over_gloo():
+    """The N > 1 data path on the hardware this box has: two rank processes, each running the HIP chain on its contiguous
+    slice of a 7-frame batch (both on GPU 0 - RCCL refuses two ranks on one device, so the record gather goes over gloo;
+    the 8-GPU RCCL run is the driver's) - every rank ends up with the whole batch in frame order, byte-identical to one
+    process doing all 7 frames."""
+    import socket
+    import numpy as np
+    import torch.multiprocessing as mp
+    from perception_amd import capi, synth, templates
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_rank_on_gpu0, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=600) for _ in range(2))
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    frames = np.stack([synth.frame(i) for i in range(7)], 0)
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=7)
+    try:
+        ctx.set_template(0, templates.template_xyz32(**templates.DEFAULT_TEMPLATE))
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        ref = capi.results_to_array(ctx.process_batch(frames, prm)[0]).tobytes()
+    finally:
+        ctx.close()
+    assert got[0] == got[1] == ref
