@@ -384,3 +384,47 @@ def test_surface_frame_known_answer(O, prm):
     flat = pts[np.abs((pts - t) @ R[:, 2] - 0.03) < 0.001]
     st, _ = O.surface_frame(flat, table_normal, prm)
     assert st == capi.CD_ERR_NO_MODEL
+
+
+def test_icp_initial_guess_known_answers(O, template):
+    """pcl::Registration::align(output, guess) (opt-in here, cd_params.icp_use_guess; the reference's authors prepared it at
+    icp.cpp:130-134,165-167): the identity as a guess is the plain align(output); a guess G moves the source once, so
+    align(src, G) is align(G src) with final = T' G (same iterations, same fitness, aligned cloud identical); a guess close to
+    the answer cuts the iteration count."""
+    rng = np.random.RandomState(11)
+    R = rot_xyz(np.deg2rad(4.0), np.deg2rad(-3.0), np.deg2rad(6.0))
+    t = np.array([0.012, -0.02, 0.35])
+    src = ((template[::4].astype(np.float64) + rng.normal(0, 2e-4, (len(template[::4]), 3))) @ R.T + t).astype(np.float32)
+    prm = capi.default_params()
+    s0, r0, a0 = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert s0 == 0 and r0.converged == 1
+    # identity guess == no guess, bit for bit
+    prm.icp_use_guess = capi.CD_GUESS_PARAMS
+    prm.icp_guess[:] = list(np.eye(4, dtype=np.float32).ravel())
+    s1, r1, a1 = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert (r1.iterations, r1.converged, r1.fitness, list(r1.T)) == (r0.iterations, r0.converged, r0.fitness, list(r0.T))
+    assert np.array_equal(a0.view(np.uint32), a1.view(np.uint32))
+    # a guess = the inverse of the (slightly wrong) known motion
+    G = np.eye(4)
+    Rg = rot_xyz(np.deg2rad(3.5), np.deg2rad(-2.5), np.deg2rad(5.0))
+    G[:3, :3] = Rg.T
+    G[:3, 3] = -Rg.T @ (t + [0.002, -0.001, 0.003])
+    Gf = G.astype(np.float32)
+    prm.icp_guess[:] = list(Gf.ravel())
+    s2, r2, a2 = O.icp(template, src, prm, nn_mode=1, want_aligned=True)
+    assert s2 == 0 and r2.converged == 1 and r2.iterations < r0.iterations
+    truth = np.eye(4)
+    truth[:3, :3], truth[:3, 3] = R, t
+    assert np.linalg.norm(np.array(r2.pose).reshape(4, 4) - truth) < 2e-3          # pose = inverse of final, guess included
+    # ... equals the registration of the pre-moved source, composed with the guess
+    moved = np.stack([((Gf[i, 0] * src[:, 0] + Gf[i, 1] * src[:, 1]) + Gf[i, 2] * src[:, 2]) + Gf[i, 3] for i in range(3)], 1).astype(np.float32)
+    prm.icp_use_guess = capi.CD_GUESS_NONE
+    s3, r3, a3 = O.icp(template, moved, prm, nn_mode=1, want_aligned=True)
+    assert (r3.iterations, r3.converged) == (r2.iterations, r2.converged)
+    assert np.array_equal(a2.view(np.uint32), a3.view(np.uint32))
+    T3 = np.array(r3.T, np.float32).reshape(4, 4)
+    comp = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            comp[i, j] = ((T3[i, 0] * Gf[0, j] + T3[i, 1] * Gf[1, j]) + T3[i, 2] * Gf[2, j]) + T3[i, 3] * Gf[3, j]
+    assert np.allclose(np.array(r2.T, np.float32).reshape(4, 4), comp, atol=2e-6)   # (the oracle folds the guess in step by step)
