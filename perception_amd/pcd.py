@@ -1,4 +1,4 @@
-"""PCD v0.7 reader/writer (ASCII and binary), replacing pcl::io::loadPCDFile for the
+"""PCD v0.7 reader/writer (ASCII, binary and binary_compressed), replacing pcl::io::loadPCDFile for the
 templates (reference: cuboid_detection/src/iterative_closest_point.cpp:159,
 object_detection/src/object_pose_detection.cpp:398)."""
 import numpy as np
@@ -7,8 +7,36 @@ _NP = {("F", 4): np.float32, ("F", 8): np.float64, ("U", 1): np.uint8, ("U", 2):
        ("U", 4): np.uint32, ("I", 1): np.int8, ("I", 2): np.int16, ("I", 4): np.int32}
 
 
+def lzf_decompress(src, out_len):
+    """LZF (the codec of DATA binary_compressed): a control byte c < 32 copies c+1 literals; otherwise a back reference of
+    length (c >> 5) + 2 (a length field of 7 takes one more byte) at distance ((c & 31) << 8 | next) + 1."""
+    out = bytearray()
+    i, n = 0, len(src)
+    while i < n:
+        c = src[i]
+        i += 1
+        if c < 32:
+            out += src[i:i + c + 1]
+            i += c + 1
+        else:
+            ln = c >> 5
+            if ln == 7:
+                ln += src[i]
+                i += 1
+            ref = len(out) - (((c & 31) << 8) | src[i]) - 1
+            i += 1
+            if ref < 0:
+                raise ValueError("corrupt LZF stream")
+            for _ in range(ln + 2):              # may overlap its own output: byte by byte
+                out.append(out[ref])
+                ref += 1
+    if len(out) != out_len:
+        raise ValueError("LZF stream decodes to %d bytes, header says %d" % (len(out), out_len))
+    return bytes(out)
+
+
 def read_pcd(path):
-    """Returns (fields dict name -> 1-D array, header dict).  DATA ascii|binary."""
+    """Returns (fields dict name -> 1-D array, header dict).  DATA ascii|binary|binary_compressed."""
     with open(path, "rb") as f:
         raw = f.read()
     hdr, pos = {}, 0
@@ -43,8 +71,17 @@ def read_pcd(path):
         rec = np.frombuffer(raw, dtype=dt, count=npts, offset=pos)
         for nm in names:
             out[nm] = np.array(rec[nm])
+    elif mode == "binary_compressed":
+        # u32 compressed size, u32 raw size, LZF stream; the raw block is field-major (all x, then all y, ...)
+        csz, usz = np.frombuffer(raw, dtype="<u4", count=2, offset=pos)
+        blob = lzf_decompress(raw[pos + 8:pos + 8 + int(csz)], int(usz))
+        off = 0
+        for nm, sz, ty, ct in zip(names, sizes, types, counts):
+            a = np.frombuffer(blob, dtype=_NP[(ty, sz)], count=npts * ct, offset=off)
+            out[nm] = np.array(a if ct == 1 else a.reshape(npts, ct))
+            off += npts * ct * sz
     else:
-        raise ValueError("unsupported PCD DATA mode %r (binary_compressed is not produced by the reference)" % mode)
+        raise ValueError("unsupported PCD DATA mode %r" % mode)
     return out, hdr
 
 

@@ -130,6 +130,7 @@ def test_binary_compressed(tool, tmp_path):
     p.write_bytes(_header(["x", "y", "z", "rgb"], [4, 4, 4, 4], list("FFFF"), [1, 1, 1, 1], n, "binary_compressed") + struct.pack("<II", len(comp), len(soa)) + comp)
     got, _ = _load(tool, p, tmp_path)
     assert np.array_equal(got.view(np.uint32), xyz.view(np.uint32))
+    assert np.array_equal(pcd.read_xyz(str(p)).view(np.uint32), xyz.view(np.uint32))      # the Python reader agrees
     # all-zero z and rgb columns written as ONE back reference chain: literal 0x00, then references of distance 1
     zeros = 2 * 4 * n                      # bytes of the z and rgb columns
     xy = xyz[:, 0].tobytes() + xyz[:, 1].tobytes()
@@ -153,6 +154,7 @@ def test_binary_compressed(tool, tmp_path):
     want = xyz.copy()
     want[:, 2] = 0
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(pcd.read_xyz(str(p)).view(np.uint32), want.view(np.uint32))
 
 
 def test_errors_are_reported(tool, tmp_path):
