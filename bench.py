@@ -16,10 +16,12 @@ import os
 import sys
 import time
 
-# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  RCCL creates streams of its own, and with 4
-# queues the two in-flight batches' streams end up sharing one queue - their kernels then run strictly one after the
-# other and the overlap (12.8 -> 14.4 ms per batch) is gone.  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues per priority level (default 4); streams that share a queue run
+# strictly one after the other.  Five batches in flight need five queues (4 -> 8: 42 k -> 46 k frames/s, tools/ab_hwq.sh);
+# config 5's six batches have two low-priority ICP streams each, and with 8 queues four of those twelve streams share
+# one (rocprofv3 kernel trace: a batch's k_icp_pipe starts when another batch's k_icp_pipe_big ends) - 16 there.  Must be
+# set before the HIP runtime initialises: main() does it once the arguments are known.
+DEFAULT_HW_QUEUES = {3: "8", 5: "16"}
 
 import numpy as np
 
@@ -220,7 +222,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to use, one rank process per GPU (default: WORLD_SIZE or 1)")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300, about 2.5 s of timed region)")
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (BASELINE config 3: 256; config 5: 8)")
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (BASELINE config 3: 256; config 5: 64 - the config names no batch size; 8 was round 2's choice, tools/sweep_c5_frames.sh)")
     ap.add_argument("--config", type=int, default=3, choices=(3, 5),
                     help="3: the headline workload (256 D435 frames per GPU, one template); 5: the multi-template stress of "
                          "BASELINE config 5 (1 M-point frames, five cuboids, five templates, every cluster x every template)")
@@ -238,14 +240,14 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial; "
-                         "default 5, config 5: 6 - measured, DESIGN.md section 6)")
+                         "default 5, config 5: 4 - measured, DESIGN.md section 6)")
     args = ap.parse_args()
     if args.frames is None:
-        args.frames = 256 if args.config == 3 else 8
+        args.frames = 256 if args.config == 3 else 64
     if args.steps is None:
-        args.steps = 300 if args.config == 3 else 40
+        args.steps = 300 if args.config == 3 else 12
     if args.inflight is None:
-        args.inflight = 5 if args.config == 3 else 6
+        args.inflight = 5 if args.config == 3 else 4
     if args.steps < 1 or args.warmup < 0 or args.frames < 1:
         raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 
@@ -261,6 +263,7 @@ def main():
     if args.dry_run:
         return dry_run(rank, local_rank, world)
 
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", DEFAULT_HW_QUEUES[args.config])
     # host-side inputs first (fork pool must not follow GPU init)
     frames = make_frames(rank * F, F, args.config)
 
@@ -337,10 +340,23 @@ def main():
     if args.warmup:
         run_steps(args.warmup)
     fence()
+    dbg_lib = capi.load_library()
+    dbg_stats = None
+    if hasattr(dbg_lib, "cd_debug_icp_stats"):       # only a -DCD_TIMERS build (CUBOID_HIP_LIB=.../libtimers.so) exports it
+        import ctypes
+        dbg_stats = (ctypes.c_ulonglong * 16)()
+        dbg_lib.cd_debug_icp_stats(dbg_stats, 1)
     t0 = time.perf_counter()
     allrec, timings = run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
+    cu_fill = None
+    if dbg_stats is not None:
+        dbg_lib.cd_debug_icp_stats(dbg_stats, 1)
+        o = list(dbg_stats)
+        if o[7]:   # persistent ICP workgroups hold a whole CU each: their busy time (100 MHz clock) over wall time x 256 CUs
+            cu_fill = {"icp_workgroups": o[7], "busy_ms_mean": o[14] / o[7] / 1e5, "busy_ms_max": o[15] / 1e5,
+                       "cu_time_frac": o[14] / 1e8 / (elapsed * 256.0)}
     icp_ms = icp_launches = 0.0
     stage = np.zeros(5)
     for t in timings:
@@ -572,6 +588,7 @@ def main():
                                               "cd_ground_plane = ground_plane_segmentation's callback (gps.cpp:43-112) as one call incl. the download of "
                                               "the kept records; host wall clock of the synchronous C-ABI call"} if len(lat_host) > 2 else None),
             "guess_leg": guess_leg,
+            "cu_fill_debug": cu_fill,
             "verified": verified,
             "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "
                              "byte-identical to a strictly serial pass run after the timed region",

@@ -85,7 +85,6 @@ class BatchPipeline:
         self._results = [(capi.CdFrameResult * max_frames)() for _ in range(self.inflight)]
         self._busy = [None] * self.inflight
         self._pool = ThreadPoolExecutor(self.inflight)
-        self._next = 0
 
     def _run(self, i, d_ptr, stride, n_points, n_frames, prm):
         cx, res = self.contexts[i], self._results[i]
@@ -94,10 +93,14 @@ class BatchPipeline:
 
     def submit(self, d_ptr, stride, n_points, n_frames, prm):
         """Queue one batch that is already resident in device memory (d_ptr: device pointer of F x N records)."""
-        i = self._next
-        self._next = (i + 1) % self.inflight
-        if self._busy[i] is not None:
-            self._busy[i].result()          # a context runs one batch at a time
+        # a context runs one batch at a time: take a free one, else wait for the first to finish (batches differ in length: a
+        # fixed rotation would hold the submission behind the slowest)
+        from concurrent.futures import FIRST_COMPLETED, wait
+        free = [j for j in range(self.inflight) if self._busy[j] is None or self._busy[j].done()]
+        if not free:
+            wait(self._busy, return_when=FIRST_COMPLETED)
+            free = [j for j in range(self.inflight) if self._busy[j].done()]
+        i = free[0]
         fut = self._pool.submit(self._run, i, d_ptr, stride, n_points, n_frames, prm)
         self._busy[i] = fut
         return fut

@@ -72,7 +72,7 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 1;                                              // clusters per workgroup a persistent ICP launch is sized for (CUBOID_ICP_CPW): 2 fills both pipeline slots
-    int icp_big_weight = 4;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; measured on config 5)
+    int icp_big_weight = 0;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; 0 = by the launch's regime, measured on config 5)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
     std::shared_ptr<const struct PreparedTemplate> tpl_prep[CD_MAX_TEMPLATES];   // host copies (shared across contexts)
@@ -600,7 +600,12 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         // chip, every group gets workgroups in proportion to its points (a query against a template in global memory
         // counted BIG_WEIGHT times), at least one, no more than it has clusters.
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
-        const long long BIG_WEIGHT = std::max(1, c->icp_big_weight);
+        // (while every problem can have a workgroup of its own the launch lasts as long as its longest cluster, and those are the
+        // global-memory ones: 4; with more problems than workgroups it is their throughput that counts, 1.6 x the LDS kernel's
+        // cost per workgroup plus the longer tail: 2 - config 5 at 8 frames per batch 4 > 2 by 5 %, at 64 frames 2 > 4 by 6 %)
+        int live_all = 0;
+        for (const TplGroup& g : groups) if (g.kind) live_all += g.live;
+        const long long BIG_WEIGHT = c->icp_big_weight > 0 ? c->icp_big_weight : (live_all <= wg_cap ? 4 : 2);
         const int cpw = std::max(1, c->icp_cpw);
         int* tab = c->h_wgtab;   // pinned: the copy below is asynchronous
         int ntab = 0;
@@ -1244,7 +1249,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(1, std::atoi(m));
-    if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(1, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_FORCE_SCAN_STALL")) c->force_stall = std::max(0, std::atoi(m));

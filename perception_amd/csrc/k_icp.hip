@@ -201,6 +201,17 @@ extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef CD_STATS
+// far queries (seed ball wider than the grid walk's reach) by iteration class (0: it < 3, 1: it < 16, 2: later) and by the
+// radius of the seed ball in grid cells (bucket 15: 15 or more)
+__device__ unsigned long long g_icp_rhist[48];
+extern "C" int cd_debug_icp_rhist(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_icp_rhist), sizeof(g_icp_rhist)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[48] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_icp_rhist), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
 #ifdef CD_ITSTATS
 __device__ unsigned long long g_icp_it[32][4];   // per ICP iteration (31 = fitness pass): pass cycles, passes, far queries, patches visited
 extern "C" int cd_debug_icp_it(unsigned long long* out, int reset) {
@@ -1684,6 +1695,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     if (ballot64(near)) grid_search<KSH, !BIG>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
+                    if (lane < nk && !near && phase == PH_ITER)
+                        atomicAdd(&g_icp_rhist[(it < 3 ? 0 : it < 16 ? 16 : 32) + min(15, (int)(rr * g.inv))], 1ull);
 #endif
                     CD_PHASE(2)
                     if constexpr (BIG) {
