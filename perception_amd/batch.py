@@ -70,8 +70,9 @@ class BatchPipeline:
     there.  Each in-flight batch gets its own context (stream + device arena + pinned mirrors) and its own host
     thread - the C-ABI call is synchronous like the PCL calls it replaces, ctypes drops the GIL while it runs - and
     the GPU overlaps the streams.  Results are identical to processing the batches one after another.
-    The streams must land on different hardware queues: export GPU_MAX_HW_QUEUES=8 (HIP's default of 4 is not enough
-    once RCCL has created its own streams) before the HIP runtime starts, as bench.py does.
+    The streams must land on different hardware queues: export GPU_MAX_HW_QUEUES=8 (HIP's default of 4 is not enough:
+    streams that share a queue run one after the other; 16 for multi-template batches, whose contexts have two more
+    streams each) before the HIP runtime starts, as bench.py does.
 
     submit() returns a Future of (records uint8[F, FRAME_RESULT_BYTES], CdTiming)."""
 
