@@ -319,3 +319,32 @@ def test_config5_one_million_points_five_templates(O, mode, monkeypatch):
         assert len(set(picked)) >= 3      # the templates really compete: different cuboids pick different templates
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "pipe"])
+@pytest.mark.parametrize("m", [7552, 7615, 7616, 7617, 7680, 65535, 65536])
+def test_template_sizes_at_the_kernel_limits(O, m, mode, monkeypatch):
+    """Template sizes either side of the kernels' limits: 7616 points is the last template whose image fits LDS (k_icp_pipe;
+    7615 leaves one pad point in its last 64-point run, 7552 none), 7617 the first that stays in global memory
+    (k_icp_pipe_big), 65535 the last a 16-bit position can address and 65536 the first that takes the sliced driver.  Random
+    subsets of a denser cuboid template, two frames; every size gives the oracle's bits."""
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    dense = templates.template_xyz32(length=0.2, width=0.1, height=0.03, density=0.0006 if m > 8000 else 0.0018)
+    assert len(dense) > m
+    rng = np.random.default_rng(m)
+    tpl = np.ascontiguousarray(dense[np.sort(rng.choice(len(dense), m, replace=False))])
+    frames = np.stack([synth.frame(i) for i in (1, 4)], 0)
+    prm = capi.default_params()
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, tpl)
+        res, _, _ = ctx.process_batch(frames, prm)
+        for f in range(len(frames)):
+            ro = O.process_frame(frames[f], prm, tpl)["result"]
+            assert res[f].n_clusters == ro.n_clusters and ro.n_clusters > 0
+            for k in range(min(ro.n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME)):
+                a, b = res[f].clusters[k], ro.clusters[k]
+                assert a.iterations == b.iterations and list(a.T) == list(b.T) and a.fitness == b.fitness, (m, mode, f, k)
+    finally:
+        ctx.close()
