@@ -348,3 +348,58 @@ def test_template_sizes_at_the_kernel_limits(O, m, mode, monkeypatch):
                 assert a.iterations == b.iterations and list(a.T) == list(b.T) and a.fitness == b.fitness, (m, mode, f, k)
     finally:
         ctx.close()
+
+
+def _hard_geometry_cases(template):
+    """(name, template, source) triples that leave the comfortable range of the search structures"""
+    from conftest import rot_xyz
+    rng = np.random.default_rng(11)
+    R = rot_xyz(0.03, -0.02, 0.04)
+    pick = lambda t, n: t[rng.integers(0, len(t), n)]
+    cases = []
+    # coordinates near 300 m: the moments leave the fast fixed-point conversion's range (|coordinate| >= 256), float spacing is 3e-5
+    off = np.array([300.0, -280.0, 290.0], np.float32)
+    cases.append(("300 m away", template + off, ((pick(template, 700) - template.mean(0)) @ R.T + template.mean(0) + 0.003).astype(np.float32) + off))
+    # a flat template: the uniform grid is one cell thick
+    g = np.arange(0, 0.12, 0.002, dtype=np.float32)
+    flat = np.stack(np.meshgrid(g, g, [np.float32(0.5)], indexing="ij"), -1).reshape(-1, 3)
+    cases.append(("flat template", flat, (pick(flat, 500) @ R.T + [0.002, -0.001, 0.004]).astype(np.float32)))
+    # five template points: fewer than a run, fewer than the k-d search has lanes
+    few = template[[0, 1000, 2000, 3000, 4000]]
+    cases.append(("5-point template", few, (pick(template, 300) + np.float32(0.001)).astype(np.float32)))
+    # every template point twice (exact ties on distance between different original indices), shuffled
+    dup = np.concatenate([template[::2], template[::2]])[rng.permutation(2 * len(template[::2]))]
+    cases.append(("duplicated points", dup, (pick(template, 900) @ R.T + np.float32(0.002)).astype(np.float32)))
+    # source a metre away from the template: every query is far in every iteration until the centroids meet
+    cases.append(("1 m apart", template, (pick(template, 600) @ R.T + [1.0, 0.5, -0.8]).astype(np.float32)))
+    # the same oddities on a template that stays in global memory (k_icp_pipe_big in pipe mode)
+    from perception_amd import templates as T
+    big = T.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)
+    cases.append(("big, 300 m away", big + off, ((pick(big, 800) - big.mean(0)) @ R.T + big.mean(0) - 0.002).astype(np.float32) + off))
+    bdup = np.concatenate([big[::2], big[::2]])[rng.permutation(2 * len(big[::2]))]
+    cases.append(("big, duplicated points", bdup, (pick(big, 800) @ R.T + np.float32(0.003)).astype(np.float32)))
+    return cases
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["auto", "sliced", "cluster", "pipe"])
+def test_icp_hard_geometry_in_every_driver(O, template, mode, monkeypatch):
+    """Coordinates beyond the fast fixed-point range, a one-cell-thick grid, a template smaller than a run, exact distance
+    ties between different original indices, sources a metre away - LDS-resident and global-memory templates, every driver:
+    iterations, transform bits and fitness equal the oracle's."""
+    monkeypatch.setenv("CUBOID_ICP_MODE", mode)
+    ctx = capi.Context(max_points=8192, max_frames=1)
+    try:
+        for slot, (name, tpl, src) in enumerate(_hard_geometry_cases(template)):
+            tpl = np.ascontiguousarray(tpl, np.float32)
+            ctx.set_template(slot % capi.CD_MAX_TEMPLATES, tpl)
+            prm = capi.default_params()
+            prm.icp_max_iterations = 50
+            st, res, al = ctx.icp(slot % capi.CD_MAX_TEMPLATES, src, prm, want_aligned=True)
+            s0, r0, a0 = O.icp(tpl, src, prm, nn_mode=1, want_aligned=True)
+            assert st == s0, (mode, name)
+            assert (res.iterations, res.converged) == (r0.iterations, r0.converged), (mode, name)
+            assert list(res.T) == list(r0.T) and res.fitness == r0.fitness, (mode, name)
+            assert np.array_equal(al.view(np.uint32), a0.view(np.uint32)), (mode, name)
+    finally:
+        ctx.close()
