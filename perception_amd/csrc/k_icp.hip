@@ -105,20 +105,29 @@ __device__ void jacobi_svd3(const float A[3][3], float U[3][3], float S[3], floa
             for (int r = 0; r < 3; ++r) U[r][i] *= f;
         }
     }
-    for (int i = 0; i < 3; ++i) {
-        int pos = i;
-        float mxv = S[i];
-        for (int k = i + 1; k < 3; ++k)
-            if (S[k] > mxv) { mxv = S[k]; pos = k; }
-        if (mxv == 0.f) break;
-        if (pos != i) {
-            float t = S[i]; S[i] = S[pos]; S[pos] = t;
-            for (int r = 0; r < 3; ++r) {
-                t = U[r][i]; U[r][i] = U[r][pos]; U[r][pos] = t;
-                t = V[r][i]; V[r][i] = V[r][pos]; V[r][pos] = t;
-            }
+    // Eigen's selection sort of the singular values (first maximum of S[i..2] goes to i; stops at a zero maximum), written out
+    // with constant indices: a run-time column index would put U, V and S into scratch memory (three dependent round trips
+    // per solve)
+#define CD_SWAP_COLS(a, b)                                                  \
+    {                                                                       \
+        float t_ = S[a]; S[a] = S[b]; S[b] = t_;                            \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                     \
+            t_ = U[r][a]; U[r][a] = U[r][b]; U[r][b] = t_;                  \
+            t_ = V[r][a]; V[r][a] = V[r][b]; V[r][b] = t_;                  \
+        }                                                                   \
+    }
+    {
+        int pos = 0;
+        float mxv = S[0];
+        if (S[1] > mxv) { mxv = S[1]; pos = 1; }
+        if (S[2] > mxv) { mxv = S[2]; pos = 2; }
+        if (mxv != 0.f) {
+            if (pos == 1) CD_SWAP_COLS(0, 1)
+            else if (pos == 2) CD_SWAP_COLS(0, 2)
+            if (S[2] > S[1]) CD_SWAP_COLS(1, 2)   // (a zero maximum here means S[1] == S[2] == 0: nothing to swap either way)
         }
     }
+#undef CD_SWAP_COLS
     for (int i = 0; i < 3; ++i) S[i] *= scale;
 }
 __device__ __forceinline__ float det3(const float m[3][3]) {
