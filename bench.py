@@ -476,11 +476,13 @@ def main():
     # rank's batch on an otherwise idle GPU.
     verified = None
     serial_rec = None
+    serial_t = None
     if not args.no_verify:
         fence()
         res = (capi.CdFrameResult * F)()
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
         serial_rec = capi.results_to_array(res).copy()
+        serial_t = ctx.timing()
         ok = bool(np.array_equal(serial_rec, allrec[rank * F:(rank + 1) * F]))
         if use_dist:
             tv = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -542,6 +544,18 @@ def main():
                     pass
             if issue >= 0.6:
                 bound = "valu"
+        # With M batches in flight the persistent launches of several batches share the chip: the per-launch duration above is
+        # then longer than the kernel's cost.  Two more figures: how many such launches run at a time on average (sum of their
+        # durations over the wall time), and the duration of ONE launch on an otherwise idle GPU - the serial pass of the
+        # self-check, HIP events on the context's stream like the timed launches.
+        overlap = (icp_ms * 1e-3) / elapsed if elapsed > 0 else None
+        exclusive = None
+        if serial_t is not None and serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0:
+            exclusive = {"avg_launch_ms": serial_t.icp_kernel_ms,
+                         "achieved": per_launch_bytes / (serial_t.icp_kernel_ms * 1e-3) / 1e9,
+                         "frac": per_launch_bytes / (serial_t.icp_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "note": "one launch of the same kernel on the same batch with nothing else on the GPU (the strictly serial "
+                                 "pass of the self-check, after the timed region)"}
         out = {
             "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -563,10 +577,13 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
                          "avg_launch_ms": avg_launch_ms, "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "launches_in_flight": overlap, "exclusive": exclusive,
                          "valu": valu,
-                         "note": "achieved/peak/frac: algorithmic bytes of the dominant kernel over its HIP-event duration against the HBM peak, as the "
-                                 "contract defines them; `bound` is what the SQ counters say limits it (valu: f32 vector issue, see roofline.valu - its "
-                                 "working set is LDS/L2-resident), DESIGN.md section 4"},
+                         "note": "achieved/peak/frac: algorithmic bytes of the dominant kernel over its HIP-event duration in the timed region against "
+                                 "the HBM peak, as the contract defines them - with several batches in flight `launches_in_flight` of these "
+                                 "launches share the chip at any time, so that duration is longer than the kernel's cost (`exclusive`: one "
+                                 "launch alone); `bound` is what the SQ counters say limits it (valu: f32 vector issue, see roofline.valu - "
+                                 "its working set is LDS/L2-resident), DESIGN.md section 4"},
             "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
                            "note": "exact search by pruning (lane-per-query grid walk for near queries, wave-per-query k-d patch search for far ones): "
