@@ -483,6 +483,11 @@ def main():
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
         serial_rec = capi.results_to_array(res).copy()
         serial_t = ctx.timing()
+        if M > 1:   # (once more for the timing: the first pass after the pipelined region still finds the other contexts' data in L2)
+            ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
+            t2 = ctx.timing()
+            if 0 < t2.icp_kernel_ms < serial_t.icp_kernel_ms:
+                serial_t = t2
         ok = bool(np.array_equal(serial_rec, allrec[rank * F:(rank + 1) * F]))
         if use_dist:
             tv = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
