@@ -240,7 +240,8 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial; "
-                         "default 5, config 5: 4 - measured, DESIGN.md section 6)")
+                         "default 5 (a long run gains 2-3 %% more from 6, a 20-step run loses as much to the longer fill and drain), config 5: 4 - "
+                         "measured, DESIGN.md section 6)")
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 256 if args.config == 3 else 64

@@ -26,11 +26,13 @@ constexpr int MAX_HYP = 1024 + 16;         // plane_max_iterations+1 hypotheses 
 constexpr int CELL_BUCKETS = 1 << 16;      // cluster spatial hash buckets per frame
 constexpr int ICP_TPL_CHUNK = 2048;        // template points staged in LDS at a time (32 KiB)
 constexpr int ICP_SUB = 64;                // template run length that carries one pruning box
-#if defined(CD_PIPE_SLOTS) && CD_PIPE_SLOTS > 2
-constexpr int ICP_TPL_LDS = 7552;          // (experiment builds with a third pipeline slot: one run less, the slot needs its LDS)
-#else
-constexpr int ICP_TPL_LDS = 7616;          // template points resident in LDS (119 runs, 119 KiB)
+#ifndef CD_PIPE_SLOTS
+#define CD_PIPE_SLOTS 4                    // most clusters a workgroup of k_icp_pipe / k_icp_pipe_big can keep in flight (IcpParams::pipe_slots)
 #endif
+// template points resident in LDS: 119 runs (119 KiB) with two pipeline slots, which leave 288 bytes of the CU's 160 KiB;
+// slots three to six (312 B each: state + moment sums) fit into ONE run of the image (64 x (16 + 2) B) less
+static_assert(CD_PIPE_SLOTS >= 1 && CD_PIPE_SLOTS <= 6, "LDS budget of k_icp_pipe");
+constexpr int ICP_TPL_LDS = CD_PIPE_SLOTS <= 2 ? 7616 : 7552;
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS
@@ -138,6 +140,8 @@ struct IcpParams {
     int32_t max_iter;
     float grid_rc;         // lane-per-query grid search for seed balls up to grid_rc cells wide (tuning only)
     double trans_eps, rel_mse, rot_thr, abs_mse;
+    int32_t pipe_slots;    // k_icp_pipe / k_icp_pipe_big: clusters a workgroup keeps in flight (1 .. CD_PIPE_SLOTS; scheduling only)
+    int32_t pad_;
 };
 
 // ---------------------------------------------------------------------------------

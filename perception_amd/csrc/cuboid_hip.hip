@@ -71,7 +71,8 @@ struct cd_context {
     int n_cu = 256;
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
-    int icp_cpw = 1;                                              // clusters per workgroup a persistent ICP launch is sized for (CUBOID_ICP_CPW): 2 fills both pipeline slots
+    int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    int icp_slots = 0;                                            // CUBOID_ICP_SLOTS: clusters in flight per workgroup, 1 .. CD_PIPE_SLOTS (0: by regime)
     int icp_big_weight = 0;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; 0 = by the launch's regime, measured on config 5)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
     int tpl_cap = 0, tpl_used = 0;
@@ -579,6 +580,21 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     ip.rel_mse = p->icp_euclidean_fitness_epsilon;
     ip.rot_thr = 1.0 - p->icp_transformation_epsilon;
     ip.abs_mse = 1e-12;
+    // Whole-cluster launches: how many clusters a workgroup keeps in flight and how many workgroups there are.  A call that has
+    // the device to itself wants every CU at work: one workgroup per CU (or per cluster), two slots, the second filled as long
+    // as clusters are left.  With other calls in flight (BatchPipeline) the chip is full anyway and what counts is the CU-time
+    // a batch costs: FOUR clusters per workgroup keep its sixteen waves supplied while one of them solves a step (no wave waits
+    // at a hand-over, no workgroup ends with one cluster alone), on a quarter as many workgroups - the other batches have the
+    // other CUs (config 3, 522 clusters: 2 x 256 -> 4 x 128 is 48.4 -> 53.3 k frames/s; grids that are not a multiple of 32 -
+    // 4 per XCD and shader engine - lose 2-4 %).
+    const bool crowded = g_calls_in_flight[c->device & (MAX_DEVICES - 1)].load() > 1;
+    ip.pipe_slots = c->icp_slots > 0 ? std::min(c->icp_slots, CD_PIPE_SLOTS) : (crowded ? CD_PIPE_SLOTS : std::min(2, CD_PIPE_SLOTS));
+    ip.pad_ = 0;
+    auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
+        if (c->icp_cpw > 0) return std::min((n_items + c->icp_cpw - 1) / c->icp_cpw, cap);
+        if (!crowded || n_items <= cap) return std::min(n_items, cap);
+        return std::max(32, std::min(cap, (n_items / ip.pipe_slots + 16) / 32 * 32));
+    };
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
@@ -606,7 +622,11 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         int live_all = 0;
         for (const TplGroup& g : groups) if (g.kind) live_all += g.live;
         const long long BIG_WEIGHT = c->icp_big_weight > 0 ? c->icp_big_weight : (live_all <= wg_cap ? 4 : 2);
-        const int cpw = std::max(1, c->icp_cpw);
+        const int cpw = std::max(1, c->icp_cpw);   // (0 = default: a group may have as many workgroups as clusters)
+        // (template groups keep two clusters in flight per workgroup whatever the regime: every group has its share of the
+        // workgroups and its own queue already, and four slots measure 3-7 % slower on config 5)
+        IcpParams ipg = ip;
+        if (c->icp_slots <= 0) ipg.pipe_slots = std::min(2, CD_PIPE_SLOTS);
         int* tab = c->h_wgtab;   // pinned: the copy below is asynchronous
         int ntab = 0;
         long long pts_all = 0;
@@ -641,10 +661,10 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         }
         if (wg_of[1] > 0)
             LAUNCH(c, launch_icp_pipe(s1, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                            c->d_queue, wg_of[1], c->d_wgtab + tab_of[1], ip));
+                            c->d_queue, wg_of[1], c->d_wgtab + tab_of[1], ipg));
         if (wg_of[2] > 0)
             LAUNCH(c, launch_icp_pipe_big(s2, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid,
-                                c->d_super, c->d_tcell, c->d_src, c->d_src0, c->d_nn, c->d_queue, wg_of[2], c->d_wgtab + tab_of[2], ip));
+                                c->d_super, c->d_tcell, c->d_src, c->d_src0, c->d_nn, c->d_queue, wg_of[2], c->d_wgtab + tab_of[2], ipg));
         if (s1 != c->stream && wg_of[1] > 0) {
             HIPCHK(c, hipEventRecord(c->ev2[2], s1));
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[2], 0));
@@ -685,10 +705,10 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         }
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
-                            c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
+                            c->d_queue, pipe_grid(ncl, wg_cap), nullptr, ip));
         else if (big_ok)
             LAUNCH(c, launch_icp_pipe_big(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_super, c->d_tcell,
-                                c->d_src, c->d_src0, c->d_nn, c->d_queue, std::min((ncl + c->icp_cpw - 1) / c->icp_cpw, wg_cap), nullptr, ip));
+                                c->d_src, c->d_src0, c->d_nn, c->d_queue, pipe_grid(ncl, wg_cap), nullptr, ip));
         else
             LAUNCH(c, launch_icp_cluster(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlo, c->d_thi, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                                c->d_queue, wg_cap, ip));
@@ -1248,7 +1268,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_cl, ncl) == hipSuccess && halloc(&c->h_cl, ncl) == hipSuccess;
     ok = ok && dalloc(&c->d_order, ncl) == hipSuccess && halloc(&c->h_order, ncl) == hipSuccess;
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
-    if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(1, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

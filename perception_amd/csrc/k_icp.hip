@@ -1462,11 +1462,8 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
 // Arithmetic is that of k_icp_cluster / k_icp_iter + k_icp_solve + k_icp_fitness (order-free
 // integer moment sums), so results are bit-identical.
 // ---------------------------------------------------------------------------------------
-#ifndef CD_PIPE_SLOTS
-#define CD_PIPE_SLOTS 2
-#endif
-constexpr int PIPE_SLOTS = CD_PIPE_SLOTS;   // clusters in flight per workgroup (2 ships; 3 was measured: DESIGN.md section 6)
-static_assert(PIPE_SLOTS >= 1 && PIPE_SLOTS <= 4, "one byte of the packed per-wave step counters per slot");
+constexpr int PIPE_SLOTS = CD_PIPE_SLOTS;   // most clusters in flight per workgroup (common.hpp); the launch says how many it uses
+static_assert(PIPE_SLOTS >= 1 && PIPE_SLOTS <= 8, "one byte of the packed per-wave step counters per slot");   // (common.hpp allows 6: LDS)
 enum { PH_ITER = 0, PH_FIT = 1, PH_EXHAUSTED = 2, PH_FILL = 3 };
 
 struct PipeSlot {
@@ -1612,7 +1609,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             PipeSlot* sl = &s_slot[sidx];
             for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
-            sl->arrived = 0; sl->epoch = 0; sl->phase = PH_FILL; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
+            sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
+            sl->phase = sidx < prm.pipe_slots ? PH_FILL : PH_EXHAUSTED;   // (a slot the launch does not use is dropped at its first visit)
         }
         // slot 0 starts with a cluster; slot 1 is filled by its first finisher, after every workgroup took its first
         pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue);
@@ -1624,7 +1622,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #endif
     // per wave: the steps it has completed on each slot (one byte per slot, mod 256: waves are never a whole step apart) and
     // the slots that still have work
-    unsigned my_ep = 0u, live = (1u << PIPE_SLOTS) - 1u;
+    unsigned long long my_ep = 0ull;
+    unsigned live = (1u << PIPE_SLOTS) - 1u;
     while (live) {
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             if (!((live >> sidx) & 1u)) continue;
@@ -1798,7 +1797,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                 if (lane == 0) __hip_atomic_store(&sl->epoch, (want + 1) & 0xff, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 CD_PHASE(3)
             }
-            my_ep = (my_ep & ~(0xffu << (8 * sidx))) | ((unsigned)((want + 1) & 0xff) << (8 * sidx));
+            my_ep = (my_ep & ~(0xffull << (8 * sidx))) | ((unsigned long long)((want + 1) & 0xff) << (8 * sidx));
         }
     }
 #ifdef CD_TIMERS

@@ -323,12 +323,13 @@ def test_config5_one_million_points_five_templates(O, mode, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "pipe"])
-@pytest.mark.parametrize("m", [7552, 7615, 7616, 7617, 7680, 65535, 65536])
+@pytest.mark.parametrize("m", [7488, 7551, 7552, 7553, 7616, 7617, 65535, 65536])
 def test_template_sizes_at_the_kernel_limits(O, m, mode, monkeypatch):
-    """Template sizes either side of the kernels' limits: 7616 points is the last template whose image fits LDS (k_icp_pipe;
-    7615 leaves one pad point in its last 64-point run, 7552 none), 7617 the first that stays in global memory
-    (k_icp_pipe_big), 65535 the last a 16-bit position can address and 65536 the first that takes the sliced driver.  Random
-    subsets of a denser cuboid template, two frames; every size gives the oracle's bits."""
+    """Template sizes either side of the kernels' limits: 7552 points (118 runs) is the last template whose image fits LDS
+    beside four pipeline slots (k_icp_pipe; 7551 leaves one pad point in its last 64-point run, 7488 none), 7553 the first
+    that stays in global memory (k_icp_pipe_big; 7616 / 7617 were that boundary with two slots), 65535 the last a 16-bit
+    position can address and 65536 the first that takes the sliced driver.  Random subsets of a denser cuboid template, two
+    frames; every size gives the oracle's bits."""
     monkeypatch.setenv("CUBOID_ICP_MODE", mode)
     dense = templates.template_xyz32(length=0.2, width=0.1, height=0.03, density=0.0006 if m > 8000 else 0.0018)
     assert len(dense) > m
