@@ -60,6 +60,7 @@ struct FrameState {
     int32_t cl_done;       // S5: the frame was clustered by k_cluster_lds (0: left to the global-memory kernels)
     int32_t crop_overflow; // single-pass crop: a y cell index did not fit its bit field (the host redoes the batch in two passes)
     int32_t scan_stalled;  // a chained scan gave up waiting for a predecessor tile (reported as CD_ERR_DEVICE)
+    int32_t n_runs;        // S1 by runs: runs of equal voxel index among the cropped points (k_voxel_runs; what the sort then moves)
 };
 
 struct CropLimits {        // double limits folded to equivalent float compares (exact)

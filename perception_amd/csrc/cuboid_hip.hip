@@ -72,6 +72,7 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    bool voxel_runs = true;                                       // CUBOID_VOXEL_RUNS=0: S1 sorts the cropped points instead of their runs of equal voxel index
     int icp_slots = 0;                                            // CUBOID_ICP_SLOTS: clusters in flight per workgroup, 1 .. CD_PIPE_SLOTS (0: by regime)
     int icp_big_weight = 0;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; 0 = by the launch's regime, measured on config 5)
     int *d_order = nullptr, *h_order = nullptr;                   // clusters, largest first
@@ -320,13 +321,23 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     const int Tsc = std::max(1, (max_nc + SORT_TILE - 1) / SORT_TILE);
     const int npass = (max_bits + RADIX_BITS - 1) / RADIX_BITS;
     int cur = 0;
-    LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp));
+    // By runs (default): the sort moves one element per run of equal voxel index among the cropped points - they are in image
+    // order, 2.4 points per run on the bench frames - and the centroid kernel reads the runs' points contiguously; the bound
+    // on the tiles is the point count (the run count is only known on the device).  CUBOID_VOXEL_RUNS=0: sort the points.
+    const bool by_runs = c->voxel_runs && npass > 0 && c->N <= (1 << 20);   // (a run's start takes 20 bits of its payload)
+    if (by_runs)
+        LAUNCH(c, cur = launch_radix_sort_runs(c->stream, c->d_key, c->d_val, c->N, F, T, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, c->d_tileA, kp));
+    else
+        LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp));
     if (cur < 0) return fail(c, CD_ERR_DEVICE, "radix sort: the scan state could not be zeroed");
     const uint32_t* vin = c->d_val[cur];   // zero passes (empty frames only): the permutation is never read
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-    LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
+    if (by_runs)
+        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
+    else
+        LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
     if (rounds_out) *rounds_out = 0;
     return CD_OK;
 }
@@ -1270,6 +1281,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
                                                          int T, int Tact, int pass, FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ ghist, int* __restrict__ state,
-                                                         KeyPack kp) {
+                                                         KeyPack kp, int use_runs) {
     __shared__ unsigned short s_wh[SORT_WAVES][RADIX];   // per-wave bin counts, then the wave's offset inside the bin
     __shared__ uint32_t s_goff[RADIX];                   // where the tile's part of each bin starts in the frame
     __shared__ uint32_t s_bstart[RADIX];                 // where each bin starts inside the tile
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     // workgroup b is tile b / F of frame b % F (see k_crop_fused): a tile's predecessors in the chained scan are long done
     const int F = gridDim.x / Tact, shift = pass * RADIX_BITS;
     const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int n = fs[f].n_c;
+    const int n = use_runs ? fs[f].n_runs : fs[f].n_c;   // (runs: the elements are k_voxel_runs' (voxel index, start | length) pairs)
     if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
 #ifdef CD_SORTDBG
@@ -230,8 +230,100 @@ int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val
     int cur = 0;
     for (int pass = 0; pass < npass; ++pass) {
         hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], pass ? val[cur] : nullptr, key[cur ^ 1],
-                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp);
+                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 0);
         kp.enabled = 0;   // later passes read voxel indices
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// ---- S1 by runs ------------------------------------------------------------------------
+// The cropped points are in image order, and neighbouring pixels of a row mostly fall into the same voxel: on the bench
+// frames 121 k cropped points are 51 k runs of equal voxel index (17.7 k voxels).  A stable sort of the RUNS by voxel index
+// leaves every voxel's points in ascending input order just as a stable sort of the points does (rule C2), with 2.4 x fewer
+// elements to move; the centroid kernel then reads each run's points contiguously (k_voxel_centroid_runs).
+// k_voxel_runs: one pass over the keys of an ordered tile - voxel index (from the absolute coordinate fields of a single-pass
+// crop), run heads (a run also ends at every multiple of 64, so its length is known inside the row), (voxel index, start |
+// length << 20) written at the frame's running run count (chained scan over the tiles), n_runs, and the digit histograms of
+// all sort passes over the run keys (what k_radix_ghist does for a sort of the points).
+constexpr int RUN_SHIFT = 20;   // start < 2^20 (CD_MAX_POINTS), length <= 64
+__global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __restrict__ kin, int N, int T, int Tact, int npass,
+                                                           FrameState* __restrict__ fs, uint32_t* __restrict__ ghist,
+                                                           int* __restrict__ state, uint32_t* __restrict__ kout,
+                                                           uint32_t* __restrict__ vout, KeyPack kp) {
+    __shared__ uint32_t s_h[SORT_MAX_PASSES][RADIX];
+    __shared__ int s_cnt[SORT_WAVES];
+    __shared__ int s_out0;
+    const int F = gridDim.x / Tact;
+    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_c;
+    if (tile * SORT_TILE >= n) return;
+    for (int q = threadIdx.x; q < SORT_MAX_PASSES * RADIX; q += SORT_BLOCK) (&s_h[0][0])[q] = 0;
+    const size_t fbase = (size_t)f * N;
+    const uint32_t* k = kin + fbase;
+    const KeyGrid g = key_grid(fs[f]);
+    const int base = tile * SORT_TILE + w * WAVE_SPAN + lane;
+    uint32_t key[ITEMS];
+    uint64_t heads[ITEMS];
+    int nvalid[ITEMS], wtot = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE;
+        const bool valid = e < n;
+        key[j] = 0xffffffffu;
+        if (valid) key[j] = kp.enabled ? voxel_key(k[e], kp, g) : k[e];
+        const uint32_t prev = (uint32_t)__shfl_up((int)key[j], 1, 64);
+        heads[j] = __ballot(valid && (lane == 0 || key[j] != prev));
+        nvalid[j] = __popcll(__ballot(valid));
+        wtot += __popcll(heads[j]);
+    }
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    int pos = 0, nheads = 0;
+    for (int q = 0; q < SORT_WAVES; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
+    if (threadIdx.x == 0) {
+        const int excl = chained_scan(state + (size_t)f * T, 1, tile, nheads, &fs[f].scan_stalled);
+        s_out0 = excl;
+        if ((tile + 1) * SORT_TILE >= n) fs[f].n_runs = excl + nheads;
+    }
+    __syncthreads();
+    const int out0 = s_out0;
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((heads[j] >> lane) & 1ull) {
+            const uint64_t above = lane == 63 ? 0ull : heads[j] & ~((2ull << lane) - 1ull);
+            const int next = above ? __ffsll((long long)above) - 1 : nvalid[j];
+            const size_t o = fbase + (size_t)(out0 + pos + __popcll(heads[j] & lt));
+            kout[o] = key[j];
+            vout[o] = (uint32_t)(base + j * WAVE) | ((uint32_t)(next - lane) << RUN_SHIFT);
+            for (int p = 0; p < npass; ++p) atomicAdd(&s_h[p][(key[j] >> (p * RADIX_BITS)) & (RADIX - 1)], 1u);
+        }
+        pos += __popcll(heads[j]);
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < npass * RADIX; q += SORT_BLOCK) {
+        const uint32_t c = (&s_h[0][0])[q];
+        if (c) atomicAdd(&ghist[(size_t)f * SORT_MAX_PASSES * RADIX + q], c);
+    }
+}
+
+// The sort of a batch by runs: key[0] holds the crop's keys; the runs go to key[1] / val[1] and the passes alternate from
+// there.  `tile_state` [F][T] (zeroed here) carries the chained scan of the run counts.  Returns the index of the buffers that
+// hold the sorted run keys / payloads, or -1 when a scan state could not be zeroed.
+int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int T, int Tact, int npass,
+                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp) {
+    if (npass <= 0) return 0;
+    if (hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(state, 0, sizeof(int) * (size_t)npass * F * Tact * RADIX, s) != hipSuccess) return -1;
+    if (hipMemsetAsync(tile_state, 0, sizeof(int) * (size_t)F * T, s) != hipSuccess) return -1;
+    hipLaunchKernelGGL(k_voxel_runs, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[0], N, T, Tact, npass, fs, ghist, tile_state, key[1],
+                       val[1], kp);
+    kp.enabled = 0;
+    int cur = 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], val[cur], key[cur ^ 1], val[cur ^ 1], N,
+                           Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 1);
         cur ^= 1;
     }
     return cur;

@@ -402,6 +402,114 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     }
 }
 
+// The same over SORTED RUNS (k_voxel_runs, k_sort.hip): keys = voxel index per run, vals = start | length << 20 of the run in the
+// cropped points, which are in input order.  A voxel's runs are consecutive in the sorted order and, the sort being stable, in
+// ascending input order; inside a run the points are consecutive: the quad replays the same sequential sum, reading each run
+// as one contiguous piece instead of one 16-byte gather per point.
+__global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* __restrict__ keys,
+                                                               const uint32_t* __restrict__ vals,
+                                                               const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
+                                                               FrameState* __restrict__ fs, int* __restrict__ state,
+                                                               float4* __restrict__ vox) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ int s_head[TILE];
+    __shared__ int s_out0;
+    const int F = gridDim.x / Tact;
+    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_runs;
+    if (tile * TILE >= n) return;
+    const size_t fbase = (size_t)f * N;
+    const uint32_t* k = keys + fbase;
+    const uint32_t* v = vals + fbase;
+    const int base = tile * TILE + w * WAVE_SPAN;
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
+        wtot += __popcll(bal[j]);
+    }
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    int pos = 0, nheads = 0;
+    for (int q = 0; q < WAVES_PER_BLOCK; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
+    if (threadIdx.x == 0) {
+        const int excl = chained_scan(state + (size_t)f * T, 1, tile, nheads, &fs[f].scan_stalled);
+        s_out0 = excl;
+        if ((tile + 1) * TILE >= n) fs[f].n_v = excl + nheads;
+    }
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) s_head[pos + __popcll(bal[j] & lt)] = base + j * WAVE + lane;
+        pos += __popcll(bal[j]);
+    }
+    __syncthreads();
+    const int out0 = s_out0;
+    const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
+    for (int h = quad; h < nheads; h += BLOCK / 4) {
+        const int e0 = s_head[h];
+        const uint32_t key = k[e0];
+        float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+        int cnt = 0;
+        // Four run records per trip (lane ql of the quad fetches record eb + ql), then the first four points of each of the
+        // four runs - sixteen independent loads in flight per quad before the first addition; runs of a voxel are contiguous
+        // in the sorted order, so the members are a prefix of the four.  The additions replay the input order: run by run,
+        // point by point.
+#define CD_ADD(P, J)                                                                                   \
+        {                                                                                              \
+            sx = __fadd_rn(sx, quad_bcast<J>(P.x)); sy = __fadd_rn(sy, quad_bcast<J>(P.y));            \
+            sz = __fadd_rn(sz, quad_bcast<J>(P.z));                                                    \
+            if (rgb_on) {                                                                              \
+                const uint32_t u = __float_as_uint(quad_bcast<J>(P.w));                                \
+                cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff); \
+            }                                                                                          \
+            ++cnt;                                                                                     \
+        }
+#define CD_RUN(I, P)                                                                                   \
+        if (len##I > 0) {                                                                              \
+            CD_ADD(P, 0)                                                                               \
+            if (len##I > 1) CD_ADD(P, 1)                                                               \
+            if (len##I > 2) CD_ADD(P, 2)                                                               \
+            if (len##I > 3) CD_ADD(P, 3)                                                               \
+            for (int i = 4; i < len##I; i += 4) {       /* longer runs: the rest, four points per trip */ \
+                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
+                if (i + ql < len##I) q = cpt[fbase + start##I + i + ql];                               \
+                CD_ADD(q, 0)                                                                           \
+                if (len##I - i > 1) CD_ADD(q, 1)                                                       \
+                if (len##I - i > 2) CD_ADD(q, 2)                                                       \
+                if (len##I - i > 3) CD_ADD(q, 3)                                                       \
+            }                                                                                          \
+        }
+        for (int eb = e0;; eb += 4) {
+            const int me = eb + ql;
+            uint32_t kk = ~key, rec = 0;
+            if (me < n) { kk = k[me]; rec = v[me]; }
+            const int mylen = kk == key ? (int)(rec >> 20) : 0, mystart = (int)(rec & ((1u << 20) - 1u));
+            const int len0 = quad_bcast_i<0>(mylen), len1 = quad_bcast_i<1>(mylen), len2 = quad_bcast_i<2>(mylen), len3 = quad_bcast_i<3>(mylen);
+            const int start0 = quad_bcast_i<0>(mystart), start1 = quad_bcast_i<1>(mystart), start2 = quad_bcast_i<2>(mystart), start3 = quad_bcast_i<3>(mystart);
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+            if (ql < len0) p0 = cpt[fbase + start0 + ql];
+            if (ql < len1) p1 = cpt[fbase + start1 + ql];
+            if (ql < len2) p2 = cpt[fbase + start2 + ql];
+            if (ql < len3) p3 = cpt[fbase + start3 + ql];
+            CD_RUN(0, p0) CD_RUN(1, p1) CD_RUN(2, p2) CD_RUN(3, p3)
+            if (len3 == 0) break;    // the voxel's runs ended inside this group of four
+        }
+#undef CD_RUN
+#undef CD_ADD
+        if (ql == 0) {
+            const float c = (float)cnt;
+            uint32_t packed = 0;
+            if (rgb_on) {
+                const int R = (int)__fdiv_rn(cr, c), G = (int)__fdiv_rn(cg, c), B = (int)__fdiv_rn(cb, c);
+                packed = ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+            }
+            vox[fbase + out0 + h] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
+        }
+    }
+}
+
 // ---- host launchers ---------------------------------------------------------------------
 void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
                        FrameState* fs, int* tile_cnt) {
@@ -429,6 +537,10 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox) {
     hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox);
+}
+void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox) {
+    hipLaunchKernelGGL(k_voxel_centroid_runs, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox);
 }
 
 }  // namespace cd

@@ -15,6 +15,8 @@ void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, in
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
+void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
 void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out);
@@ -25,6 +27,9 @@ void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int
 constexpr int SORT_MAX_PASSES_HOST = 4;
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
                       FrameState* fs, uint32_t* ghist, int* state, KeyPack kp);
+// the same sort over RUNS of equal voxel index (k_voxel_runs: 2-3 x fewer elements on organised clouds); tile_state: [F][T] ints
+int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int T, int Tact, int npass,
+                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp);
 
 // k_plane.hip
 void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,
