@@ -583,3 +583,47 @@ def test_randomised_scenes_and_parameters(O, template):
 def templates_small():
     from perception_amd import templates as T
     return T.template_xyz32(length=0.2, width=0.075, height=0.1, density=0.005)
+
+
+@pytest.mark.parametrize("path", ["runs", "points", "runs_off_for_big_contexts"])
+def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
+    """S1 sorts RUNS of equal voxel index among the cropped points by default (k_voxel_runs, k_voxel_centroid_runs);
+    CUBOID_VOXEL_RUNS=0 sorts the points (k_radix_ghist, k_voxel_centroid), and so does a context of more than 2^20 points per
+    frame (a run's start has 20 bits).  Same bits as the oracle either way, on: organised frames (runs of ~2.4 points), one
+    voxel holding 3000 consecutive points (runs are cut at every 64), keys that alternate from point to point (every run is
+    one point long), an unorganised cloud with rgb, frames in a batch."""
+    if path == "points":
+        monkeypatch.setenv("CUBOID_VOXEL_RUNS", "0")
+    rng = np.random.RandomState(12)
+    max_points = (1 << 20) + 4096 if path == "runs_off_for_big_contexts" else synth.WIDTH * synth.HEIGHT
+    cx = capi.Context(max_points=max_points, max_frames=2)
+    try:
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        clouds = [frames4[0], frames4[2]]
+        one = np.zeros((5000, 4), np.float32)
+        one[:, :3] = [0.101, 0.051, 0.501]
+        one[:3000, :3] += rng.uniform(0, 0.0039, (3000, 3)).astype(np.float32)       # 3000 consecutive points in one voxel
+        one[3000:, :3] = rng.uniform([-0.19, -0.2, 0.1], [0.19, 0.2, 0.85], (2000, 3))
+        one[:, 3] = rng.randint(0, 1 << 24, 5000).astype(np.uint32).view(np.float32)
+        clouds.append(one)
+        alt = np.zeros((4001, 4), np.float32)
+        alt[0::2, :3] = [0.1, 0.0, 0.4]
+        alt[1::2, :3] = [-0.1, 0.02, 0.6]
+        alt[:, :3] += rng.uniform(0, 0.004, (4001, 3)).astype(np.float32)
+        clouds.append(alt)
+        for pts in clouds:
+            vox, rgb, nc = cx.crop_voxel(pts, prm, want_rgb=True)
+            st, vo, ro, nco, _ = O.crop_voxel(pts, prm, want_rgb=True)
+            assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+        if path != "runs_off_for_big_contexts":
+            from perception_amd import templates
+            cx.set_template(0, templates.template_xyz32(**templates.DEFAULT_TEMPLATE))
+            batch = np.stack([frames4[1], frames4[3]], 0)
+            res, _, _ = cx.process_batch(batch, prm)
+            want = [O.crop_voxel(batch[f], prm)[1] for f in range(2)]
+            for f in range(2):
+                got = cx.frame_cloud(f, capi.CD_CLOUD_VOXELS, 16, -1)[:, :3].copy().view(np.float32)
+                assert res[f].n_voxels == len(want[f]) and np.array_equal(got.view(np.uint32), want[f].view(np.uint32))
+    finally:
+        cx.close()
