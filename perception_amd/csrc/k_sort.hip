@@ -291,13 +291,30 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __res
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        if ((heads[j] >> lane) & 1ull) {
+        const bool is_head = (heads[j] >> lane) & 1ull;
+        if (is_head) {
             const uint64_t above = lane == 63 ? 0ull : heads[j] & ~((2ull << lane) - 1ull);
             const int next = above ? __ffsll((long long)above) - 1 : nvalid[j];
             const size_t o = fbase + (size_t)(out0 + pos + __popcll(heads[j] & lt));
             kout[o] = key[j];
             vout[o] = (uint32_t)(base + j * WAVE) | ((uint32_t)(next - lane) << RUN_SHIFT);
-            for (int p = 0; p < npass; ++p) atomicAdd(&s_h[p][(key[j] >> (p * RADIX_BITS)) & (RADIX - 1)], 1u);
+        }
+        // digit histograms of the run keys.  Above the lowest digit the heads of a row (64 neighbouring pixels) nearly always
+        // share the digit: one add of their number instead of that many adds to one LDS word, which the LDS would serialise
+        // (30 % of the kernel).
+        if (heads[j]) {
+            const int first = __ffsll((long long)heads[j]) - 1;
+            for (int p = 0; p < npass; ++p) {
+                const uint32_t d = (key[j] >> (p * RADIX_BITS)) & (RADIX - 1);
+                if (p > 0) {
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+                    if (__ballot(is_head && d != d0) == 0ull) {
+                        if (lane == first) atomicAdd(&s_h[p][d0], (uint32_t)__popcll(heads[j]));
+                        continue;
+                    }
+                }
+                if (is_head) atomicAdd(&s_h[p][d], 1u);
+            }
         }
         pos += __popcll(heads[j]);
     }
