@@ -312,6 +312,8 @@ def main():
         import queue
         import threading
         q, tims, last = queue.Queue(), [], [None]
+        trace = [] if os.environ.get("CUBOID_BENCH_TRACE") else None   # debug: completion time of every step (stderr)
+        t_begin = time.perf_counter()
 
         def gatherer():
             torch.cuda.set_device(local_rank)
@@ -321,6 +323,8 @@ def main():
                     return
                 rec, t = fut.result()
                 tims.append(t)
+                if trace is not None:
+                    trace.append(time.perf_counter())
                 with torch.cuda.stream(side):   # not the NULL stream: its copies would queue behind the persistent ICP launches
                     last[0] = batch.gather_records(rec, F * world, dist if use_dist else None, dev)
 
@@ -330,6 +334,8 @@ def main():
             q.put(pipe.submit(d_frames.data_ptr(), 16, N, F, prm))   # one pass of the hot path over one batch
         q.put(None)
         th.join()
+        if trace:
+            print("bench.py trace: %d steps, completions at ms %s" % (k, " ".join("%.1f" % ((x - t_begin) * 1e3) for x in trace)), file=sys.stderr)
         return last[0], tims
 
     def fence():
