@@ -604,7 +604,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
         if (c->icp_cpw > 0) return std::min((n_items + c->icp_cpw - 1) / c->icp_cpw, cap);
         if (!crowded || n_items <= cap) return std::min(n_items, cap);
-        return std::max(32, std::min(cap, (n_items / ip.pipe_slots + 16) / 32 * 32));
+        return std::min(cap, std::max(32, (n_items / ip.pipe_slots + 16) / 32 * 32));
     };
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its

@@ -404,3 +404,34 @@ def test_icp_hard_geometry_in_every_driver(O, template, mode, monkeypatch):
             assert np.array_equal(al.view(np.uint32), a0.view(np.uint32)), (mode, name)
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("max_wg", ["2", ""])
+def test_big_template_batches_in_flight(max_wg, monkeypatch):
+    """k_icp_pipe_big with other calls on the device (the regime in which a whole-cluster launch keeps four clusters in flight
+    per workgroup): four batches of a 10 700-point template on two contexts give the records of a serial pass byte for byte -
+    with the grid capped at two workgroups (every slot refills many times) and uncapped."""
+    import torch
+    from perception_amd import batch
+    monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    if max_wg:
+        monkeypatch.setenv("CUBOID_ICP_MAX_WG", max_wg)
+    big = templates.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)
+    sets = [np.stack([synth.frame(i) for i in idx], 0) for idx in ((0, 1, 2, 3), (4, 5, 6, 7), (8, 9, 10, 11), (12, 13, 14, 15))]
+    prm = capi.default_params()
+    N = sets[0].shape[1]
+    ctx = capi.Context(max_points=N, max_frames=4)
+    ctx.set_template(0, big)
+    want = [capi.results_to_array(ctx.process_batch(s, prm)[0]).copy() for s in sets]
+    ctx.close()
+    dev = [torch.from_numpy(s).cuda() for s in sets]
+    torch.cuda.synchronize()
+    pipe = batch.BatchPipeline(N, 4, {0: big}, inflight=2)
+    try:
+        futs = [pipe.submit(d.data_ptr(), 16, N, 4, prm) for d in dev]
+        for f, w in zip(futs, want):
+            rec, _ = f.result()
+            assert np.array_equal(rec, w)
+    finally:
+        pipe.close()
