@@ -609,7 +609,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
-    // The pipelined variant (two clusters in flight per workgroup, no barrier in the iteration loop) needs one
+    // The pipelined variant (two to four clusters in flight per workgroup, no barrier in the iteration loop) needs one
     // LDS-resident gridded template shared by every cluster of the launch; otherwise k_icp_cluster runs.
     bool one_tpl = true;
     for (int k = 1; k < ncl && one_tpl; ++k) one_tpl = c->h_cl[k].tpl_off == c->h_cl[0].tpl_off && c->h_cl[k].tpl_m == c->h_cl[0].tpl_m;

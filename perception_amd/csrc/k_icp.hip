@@ -1448,17 +1448,18 @@ __global__ void __launch_bounds__(ICPT_THREADS) k_icp_cluster(int ncl, const int
 //
 // k_icp_cluster spends about a fifth of its time in the per-iteration barrier (waves of one
 // workgroup finish their share of an iteration at different times) and another tenth in the
-// single-threaded Umeyama/SVD solve that 1023 threads wait for.  Here a workgroup owns two
-// cluster slots (same template in LDS).  Every wave walks the slots round-robin:
+// single-threaded Umeyama/SVD solve that 1023 threads wait for.  Here a workgroup owns up to
+// CD_PIPE_SLOTS cluster slots (same template in LDS; the launch says how many it uses: two when it
+// has the GPU to itself, four when the GPU is shared).  Every wave walks the slots round-robin:
 //   wait until the slot's epoch says the previous step has been solved  ->  do its own share of
 //   the slot's current step (a fixed set of source points per lane, as in k_icp_cluster)  ->
 //   add its 16 fixed-point moment sums to the slot's LDS accumulators  ->  count itself arrived.
 // The wave that arrives LAST runs the solve for that step (or the fitness hand-over and the
 // refill of the slot from the global cluster queue) and bumps the epoch, while the other
-// fifteen waves are already working on the other slot.  All waves visit the same sequence of
+// fifteen waves are already working on the other slots.  All waves visit the same sequence of
 // (slot, epoch) steps and the slowest wave never waits for anything but a solve in progress, so
 // there is no circular wait; a slot whose queue ran dry is published as exhausted through the
-// same epoch mechanism and every wave leaves after seeing both slots exhausted.
+// same epoch mechanism and every wave leaves after seeing every slot exhausted.
 // Arithmetic is that of k_icp_cluster / k_icp_iter + k_icp_solve + k_icp_fitness (order-free
 // integer moment sums), so results are bit-identical.
 // ---------------------------------------------------------------------------------------
@@ -1612,7 +1613,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
             sl->phase = sidx < prm.pipe_slots ? PH_FILL : PH_EXHAUSTED;   // (a slot the launch does not use is dropped at its first visit)
         }
-        // slot 0 starts with a cluster; slot 1 is filled by its first finisher, after every workgroup took its first
+        // slot 0 starts with a cluster; the other slots are filled at their first step (PH_FILL), after every workgroup took its first
         pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue);
     }
     __syncthreads();
