@@ -598,7 +598,9 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // at a hand-over, no workgroup ends with one cluster alone), on a quarter as many workgroups - the other batches have the
     // other CUs (config 3, 522 clusters: 2 x 256 -> 4 x 128 is 48.4 -> 53.3 k frames/s; grids that are not a multiple of 32 -
     // 4 per XCD and shader engine - lose 2-4 %).
-    const bool crowded = g_calls_in_flight[c->device & (MAX_DEVICES - 1)].load() > 1;
+    // (crossover measured on config 3: with two calls in flight the two shapes tie, with three 2 x 256 wins 49.4 : 46.5 k, with
+    // four 4 x 128 wins 52.9 : 49.7 k - and the last launches of a burst, which soon have the GPU to themselves, spread out)
+    const bool crowded = g_calls_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 4;
     ip.pipe_slots = c->icp_slots > 0 ? std::min(c->icp_slots, CD_PIPE_SLOTS) : (crowded ? CD_PIPE_SLOTS : std::min(2, CD_PIPE_SLOTS));
     ip.pad_ = 0;
     auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
