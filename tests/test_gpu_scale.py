@@ -415,6 +415,7 @@ def test_big_template_batches_in_flight(max_wg, monkeypatch):
     import torch
     from perception_amd import batch
     monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    monkeypatch.setenv("CUBOID_ICP_SLOTS", "4")      # (the regime rule asks for four calls in flight; two contexts here)
     if max_wg:
         monkeypatch.setenv("CUBOID_ICP_MAX_WG", max_wg)
     big = templates.template_xyz32(length=0.2, width=0.1, height=0.075, density=0.002)

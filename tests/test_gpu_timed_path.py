@@ -43,9 +43,10 @@ def _render(lo, n):
         return np.stack(list(ex.map(synth.frame, range(lo, lo + n))), 0)
 
 
-def test_bench_config3_three_batches_in_flight_vs_oracle(O, template):
-    """Exactly what bench.py times: 256 frames per batch, default ICP mode (auto -> k_icp_pipe), BatchPipeline(inflight=3),
-    four consecutive batches (so every context is reused while the others are busy); every record vs the oracle."""
+def test_bench_config3_five_batches_in_flight_vs_oracle(O, template):
+    """Exactly what bench.py times: 256 frames per batch, default ICP mode (auto -> k_icp_pipe), BatchPipeline(inflight=5) -
+    with four or more calls on the device a launch keeps FOUR clusters in flight per workgroup on 128 workgroups - eight
+    consecutive batches (so contexts are reused while the others are busy); every record vs the oracle."""
     import torch
     from perception_amd import batch
     F = 256
@@ -59,9 +60,9 @@ def test_bench_config3_three_batches_in_flight_vs_oracle(O, template):
     dev = [torch.from_numpy(s).cuda() for s in sets]
     torch.cuda.synchronize()
     N = sets[0].shape[1]
-    pipe = batch.BatchPipeline(N, F, {0: template}, inflight=3)
+    pipe = batch.BatchPipeline(N, F, {0: template}, inflight=5)
     try:
-        order = [0, 1, 0, 1, 1, 0]
+        order = [0, 1, 0, 1, 1, 0, 0, 1]
         futs = [pipe.submit(dev[i].data_ptr(), 16, N, F, prm) for i in order]
         for step, (i, fut) in enumerate(zip(order, futs)):
             rec, tim = fut.result()
@@ -73,11 +74,16 @@ def test_bench_config3_three_batches_in_flight_vs_oracle(O, template):
         pipe.close()
 
 
+@pytest.mark.parametrize("slots", ["", "1", "3", "4"])
 @pytest.mark.parametrize("max_wg", ["1", "2", "5"])
-def test_pipe_slot_refill_with_capped_grid(O, template, max_wg, monkeypatch):
-    """k_icp_pipe on 1, 2 or 5 workgroups with ~20 clusters: every slot is refilled several times, the two slots of a
-    workgroup hold clusters at different iterations, and the last clusters leave one slot exhausted while the other
-    still works.  Records must equal the oracle's, and the sliced driver's bytes."""
+def test_pipe_slot_refill_with_capped_grid(O, template, max_wg, slots, monkeypatch):
+    """k_icp_pipe on 1, 2 or 5 workgroups with ~20 clusters: every slot is refilled several times, the slots of a
+    workgroup hold clusters at different iterations, and the last clusters leave slots exhausted while another
+    still works - with the slot count of the regime rule (two: the call has the GPU to itself) and forced to 1, 3 and 4
+    (four is what a launch uses that shares the GPU with three or more calls).  Records must equal the oracle's, and the
+    sliced driver's bytes."""
+    if slots:
+        monkeypatch.setenv("CUBOID_ICP_SLOTS", slots)
     idx = list(range(40, 50))
     frames = np.stack([synth.frame(i) for i in idx], 0)
     prm = capi.default_params()
