@@ -354,7 +354,15 @@ inline int loadPCDFile(const std::string& path, PointCloud<PointXYZ>& cloud) {
         } else if (key == "DATA" && t.size() > 1) { data = t[1]; break; }
     }
     if (data.empty()) return err("no DATA line");
-    if (npts < 0 && width >= 0) npts = width * (height >= 0 ? height : 1);     // POINTS is optional: WIDTH x HEIGHT
+    // The header is not trusted: counts are bounded by what is left of the file BEFORE anything is allocated (a malformed
+    // template must give -1, not bad_alloc / length_error out of a function the nodes call unguarded)
+    const long data_pos = std::ftell(f);
+    long file_end = data_pos;
+    if (data_pos < 0 || std::fseek(f, 0, SEEK_END) != 0 || (file_end = std::ftell(f)) < data_pos || std::fseek(f, data_pos, SEEK_SET) != 0)
+        return err("cannot size the file");
+    const size_t left = (size_t)(file_end - data_pos);
+    if (width > (1l << 31) || height > (1l << 31) || npts > (1l << 31)) return err("WIDTH / HEIGHT / POINTS out of range");
+    if (npts < 0 && width >= 0) npts = width * (height >= 0 ? height : 1);     // POINTS is optional: WIDTH x HEIGHT (each <= 2^31: no overflow)
     if (npts < 0) return err("neither POINTS nor WIDTH / HEIGHT");
     int ix = -1, iy = -1, iz = -1;
     size_t step = 0, tokens = 0;
@@ -367,7 +375,13 @@ inline int loadPCDFile(const std::string& path, PointCloud<PointXYZ>& cloud) {
         if (fd.count >= 1) { if (fd.name == "x") ix = (int)k; if (fd.name == "y") iy = (int)k; if (fd.name == "z") iz = (int)k; }
     }
     if (ix < 0 || iy < 0 || iz < 0) return err("no x / y / z fields");
-    cloud.points.resize((size_t)npts);
+    if (step == 0 || step > (1u << 20) || tokens == 0) return err("bad record size");
+    // a point takes at least `step` bytes (binary), two bytes per token (ascii: a digit and a separator); binary_compressed is
+    // checked against its own size words below
+    if (data == "binary" && (size_t)npts > left / step) return err("binary data ends early");
+    if (data == "ascii" && (size_t)npts > left / (2 * tokens) + 1) return err("ascii data ends early");
+    if (data == "binary_compressed" && (size_t)npts > ((size_t)1 << 32) / step) return err("binary_compressed: header larger than the format's 32-bit sizes");
+    try { cloud.points.resize((size_t)npts); } catch (const std::exception&) { cloud.clear(); return err("out of memory"); }
     if (data == "ascii") {
         // token positions of x, y, z within a row (a field of COUNT c contributes c tokens)
         size_t tx = 0, ty = 0, tz = 0, acc = 0;
@@ -392,7 +406,11 @@ inline int loadPCDFile(const std::string& path, PointCloud<PointXYZ>& cloud) {
         uint32_t sz[2];
         if (std::fread(sz, 4, 2, f) != 2) return err("binary_compressed: no size words");
         if ((size_t)sz[1] != step * (size_t)npts) return err("binary_compressed: uncompressed size does not match the header");
-        std::vector<unsigned char> in(sz[0]), out(sz[1]);
+        if ((size_t)sz[0] > left - (left >= 8 ? 8 : left)) return err("binary_compressed data ends early");
+        // (LZF expands a byte to at most 264 / 2 bytes: a stream this short cannot hold that many)
+        if ((size_t)sz[1] > (size_t)sz[0] * 132 + 32) return err("binary_compressed: malformed LZF stream");
+        std::vector<unsigned char> in, out;
+        try { in.resize(sz[0]); out.resize(sz[1]); } catch (const std::exception&) { cloud.clear(); return err("out of memory"); }
         if (sz[0] && std::fread(in.data(), 1, sz[0], f) != sz[0]) return err("binary_compressed data ends early");
         if (sz[1] && lzf_decompress(in.data(), in.size(), out.data(), out.size()) != out.size()) return err("binary_compressed: malformed LZF stream");
         // fields one after the other: field k occupies npts * size * count bytes starting at npts * offset_k

@@ -21,12 +21,23 @@ static int field_offset(const sensor_msgs::PointCloud2& m, const char* name) {
     for (const auto& f : m.fields) if (f.name == name) return (int)f.offset;
     return -1;
 }
+// x, y, z as FLOAT32 at byte offsets 0 / 4 / 8 and records of whole 4-byte words: what the device code reads and writes
+static bool xyz_float32_at_0_4_8(const sensor_msgs::PointCloud2& m) {
+    int seen = 0;
+    for (const auto& f : m.fields) {
+        const int want = f.name == "x" ? 0 : f.name == "y" ? 4 : f.name == "z" ? 8 : -1;
+        if (want < 0) continue;
+        if ((int)f.offset != want || f.datatype != sensor_msgs::PointField::FLOAT32) return false;
+        ++seen;
+    }
+    return seen == 3 && m.point_step >= 12 && (m.point_step & 3u) == 0;
+}
 
 void callback(const sensor_msgs::PointCloud2ConstPtr& input) {
     // The PointCloud2 blob goes to the device as it is: x,y,z float32 at offsets 0/4/8 (what every PCL point type and the
     // D435 driver use), stride = point_step.
-    if (field_offset(*input, "x") != 0 || field_offset(*input, "y") != 4 || field_offset(*input, "z") != 8) {
-        ROS_ERROR("ground_plane_segmentation: expected float32 x,y,z at byte offsets 0,4,8 of a record");
+    if (!xyz_float32_at_0_4_8(*input)) {
+        ROS_ERROR("ground_plane_segmentation: expected FLOAT32 x,y,z at byte offsets 0,4,8 of a record and a point_step that is a multiple of 4");
         return;
     }
     cd_context* ctx = pclhip::Device::instance((int)(input->width * input->height)).ctx();

@@ -89,8 +89,11 @@ bool service_callback(object_detection::ObjectDetection::Request& req, object_de
     res.success = false;
     const int id = (int)req.object_id;
     if (!input_pcl || id < 1 || id > 4 || id >= CD_MAX_TEMPLATES) return false;
-    if (field_offset(*input_pcl, "x") != 0 || field_offset(*input_pcl, "y") != 4 || field_offset(*input_pcl, "z") != 8) {
-        ROS_ERROR("object_pose_detection: expected float32 x,y,z at byte offsets 0,4,8 of a record");
+    bool xyz_ok = input_pcl->point_step >= 12 && (input_pcl->point_step & 3u) == 0;
+    for (const auto& f : input_pcl->fields)
+        if ((f.name == "x" || f.name == "y" || f.name == "z") && f.datatype != sensor_msgs::PointField::FLOAT32) xyz_ok = false;
+    if (!xyz_ok || field_offset(*input_pcl, "x") != 0 || field_offset(*input_pcl, "y") != 4 || field_offset(*input_pcl, "z") != 8) {
+        ROS_ERROR("object_pose_detection: expected FLOAT32 x,y,z at byte offsets 0,4,8 of a record and a point_step that is a multiple of 4");
         return false;
     }
     const int n = (int)(input_pcl->width * input_pcl->height);

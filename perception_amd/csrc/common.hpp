@@ -29,10 +29,11 @@ constexpr int ICP_SUB = 64;                // template run length that carries o
 #ifndef CD_PIPE_SLOTS
 #define CD_PIPE_SLOTS 4                    // most clusters a workgroup of k_icp_pipe / k_icp_pipe_big can keep in flight (IcpParams::pipe_slots)
 #endif
-// template points resident in LDS: 119 runs (119 KiB) with two pipeline slots, which leave 288 bytes of the CU's 160 KiB;
-// slots three to six (312 B each: state + moment sums) fit into ONE run of the image (64 x (16 + 2) B) less
+// template points resident in LDS: 118 runs (118 KiB) with two pipeline slots; slots three to six (312 B each: state + moment
+// sums) fit into ONE run of the image (64 x (16 + 2) B) less.  (Round 4: one run went to the eight 64-bit words per wave of
+// the pair search, k_icp.hip search_pairs - 1 KiB; rounds 2-3 held 7616 / 7552 points.)
 static_assert(CD_PIPE_SLOTS >= 1 && CD_PIPE_SLOTS <= 6, "LDS budget of k_icp_pipe");
-constexpr int ICP_TPL_LDS = CD_PIPE_SLOTS <= 2 ? 7616 : 7552;
+constexpr int ICP_TPL_LDS = CD_PIPE_SLOTS <= 2 ? 7552 : 7488;
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS
@@ -229,14 +230,29 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
+// A workgroup's place in a grid from an atomic TICKET instead of blockIdx (round 4).  The chained scans below wait for tiles
+// with smaller ids; a workgroup that holds ticket t exists only after tickets 0..t-1 were drawn, by workgroups that are
+// running or done - so every wait ends, whatever order the hardware starts a grid's workgroups in and whoever else shares
+// the GPU (several contexts in flight: until round 3 the ids came from blockIdx and the argument rested on the dispatch
+// order).  The workgroup that draws the grid's last ticket puts the counter back to zero for the next launch (the launches
+// that share a counter are ordered on one stream).  One device-scope atomic round trip before the first load; ends with a
+// workgroup barrier.  `s_ticket`: one int of LDS.
+__device__ __forceinline__ int take_ticket(int* counter, int* s_ticket) {
+    if (threadIdx.x == 0) {
+        const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == (int)(gridDim.x * gridDim.y * gridDim.z) - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_ticket = t;
+    }
+    __syncthreads();
+    return *s_ticket;
+}
 // Exclusive prefix of `tot` over the tiles 0..tile-1 of one frame by a chained scan ("decoupled look-back"): a tile publishes
 // its own total (flag 1), walks back over its predecessors adding totals until it meets an inclusive prefix (flag 2), and
 // publishes its own inclusive prefix.  state words (zeroed before the launch): flag << 30 | value; tile q's word is
 // state[q * stride] (one thread per workgroup for a scalar scan, one thread per bin for the radix scatter).
-// A workgroup only ever waits for workgroups with a smaller id when tiles are numbered in launch order, and the hardware
-// starts the workgroups of a grid in id order (per XCD queue), so the unfinished workgroup with the smallest id is always
-// running: the waits are finite.  (An atomic ticket would make that independent of the dispatch order, at the price of a
-// dependent memory round trip before the first load; the spin bound turns a wait that does not end into *gave_up = 1.)
+// A workgroup only ever waits for tiles with a smaller id, and the ids are tickets (take_ticket above): their holders are
+// running or done, so the waits are finite by construction.  (The spin bound is a guard that cannot fire any more; it still
+// turns a wait that does not end - a lost store, a faulted predecessor - into *gave_up = 1 instead of a hung GPU.)
 __device__ __forceinline__ int chained_scan(int* state, int stride, int tile, int tot, int* gave_up) {
     unsigned* st = reinterpret_cast<unsigned*>(state);
     const unsigned FLAG_TOTAL = 1u << 30, FLAG_PREFIX = 2u << 30, VALUE = (1u << 30) - 1u;

@@ -41,6 +41,7 @@ struct cd_context {
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_ghist = nullptr;
     int* d_sstate = nullptr;   // chained-scan state of the radix passes, [pass][F][tiles][256]
+    int* d_ticket = nullptr;   // ticket counter of the kernels that scan over tiles (take_ticket, common.hpp): zero between launches
     // RANSAC
     int* d_rnd = nullptr;
     float4* d_models = nullptr;
@@ -290,11 +291,14 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
         }
     }
     int st = CD_OK;
+    // (the ticket counter resets itself at the end of every launch that uses it; zeroed here too so that a call that failed
+    // half way can never leave the next one with a counter that is not zero)
+    HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
         if (kp.enabled) {
-            LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]));
+            LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0], c->d_ticket));
             LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
         } else {
             LAUNCH(c, launch_crop_count(c->stream, d_in, stride, N, F, rgb_off, lim, T, c->d_fs, c->d_tileA));
@@ -326,18 +330,18 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // on the tiles is the point count (the run count is only known on the device).  CUBOID_VOXEL_RUNS=0: sort the points.
     const bool by_runs = c->voxel_runs && npass > 0 && c->N <= (1 << 20);   // (a run's start takes 20 bits of its payload)
     if (by_runs)
-        LAUNCH(c, cur = launch_radix_sort_runs(c->stream, c->d_key, c->d_val, c->N, F, T, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, c->d_tileA, kp));
+        LAUNCH(c, cur = launch_radix_sort_runs(c->stream, c->d_key, c->d_val, c->N, F, T, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, c->d_tileA, kp, c->d_ticket));
     else
-        LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp));
+        LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp, c->d_ticket));
     if (cur < 0) return fail(c, CD_ERR_DEVICE, "radix sort: the scan state could not be zeroed");
     const uint32_t* vin = c->d_val[cur];   // zero passes (empty frames only): the permutation is never read
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
     if (by_runs)
-        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
+        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
     else
-        LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox));
+        LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
     if (rounds_out) *rounds_out = 0;
     return CD_OK;
 }
@@ -1203,7 +1207,7 @@ void cd_destroy(cd_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
-                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
+                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_ticket, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
@@ -1246,6 +1250,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
     ok = ok && dalloc(&c->d_ghist, F * SORT_MAX_PASSES_HOST * RADIX) == hipSuccess;
     ok = ok && dalloc(&c->d_sstate, (size_t)SORT_MAX_PASSES_HOST * F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
+    ok = ok && dalloc(&c->d_ticket, 4) == hipSuccess && hipMemset(c->d_ticket, 0, sizeof(int) * 4) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
     ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess && halloc(&c->h_models, F * MAX_HYP) == hipSuccess;
@@ -1830,8 +1835,9 @@ static int cd_extract_impl(cd_context* c, const void* points, size_t stride, int
         HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_rank, 0, sizeof(int) * (size_t)n, c->stream));            // marks
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)c->T, c->stream));          // chained-scan state
+        HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
         LAUNCH(c, launch_mark_indices(c->stream, c->d_label, mi, n, c->d_rank));
-        LAUNCH(c, launch_select_unmarked(c->stream, c->d_rank, n, c->d_tileA, c->d_fs, c->d_plane_idx));
+        LAUNCH(c, launch_select_unmarked(c->stream, c->d_rank, n, c->d_tileA, c->d_fs, c->d_plane_idx, c->d_ticket));
         st = sync_fs(c, 1);
         if (st) return st;
         kept = c->h_fs[0].n_plane;

@@ -660,6 +660,158 @@ __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsign
 }
 
 
+// ---------------------------------------------------------------------------------------
+// The same search as a list of (query, patch) PAIRS (round 4).  search_patches handles one far query at a time, and everything
+// a query needs is one dependent chain: five readlanes -> box tests -> ballot -> per patch (position read -> LDS round trip ->
+// point read -> LDS round trip -> distance -> minimum) -> ballot -> readlanes or three more LDS operations.  The counters say
+// what that costs (profiles/r04_valu_calibration.txt, r04_pmc_wait.txt): a wave of k_icp_pipe sits at an s_waitcnt for half of
+// its life and the vector pipe is a third used - the kernel is bound by those chains, not by issue slots.  Here the far queries
+// of a pass are taken FAR_CHUNK at a time and the phases are separated, so that independent work is in flight together:
+//   P1  per query of the chunk: readlanes, box tests, ballots - and every surviving patch is filed as a pair
+//       (slot j, query lane k, patch r) in lane `np++` of ONE vector register (v_writelane): no LDS operation at all;
+//   P2  the pairs are drained two at a time: both pairs' position reads go out together, then both point reads, then both
+//       distances; a lane whose candidate beats its query's bound lowers the query's LDS word (ds_min_u64 on slot j - the
+//       lexicographic (d2, original index) minimum of rule C5 is an unsigned 64-bit minimum of the keys, hence order-free);
+//   P3  lane-parallel: every query lane of the chunk reads its word back.
+// Same candidates, same keys, same minimum: bit-identical results.  A query that more than FAR_PAIRS patches survive (a loose
+// bound in the first iterations) is searched by search_patches' loop on its own.
+// ---------------------------------------------------------------------------------------
+constexpr int FAR_CHUNK = 8;    // far queries per chunk = 64-bit LDS words per wave
+constexpr int FAR_PAIRS = 64;   // pairs per chunk = lanes of the pair register
+
+// v[lane] = val (both wave-uniform).  (This compiler has no __builtin_amdgcn_writelane; two scalar registers in one VOP3
+// violate gfx9's constant-bus limit, so the lane select goes through M0.)
+__device__ __forceinline__ int writelane_i32(int v, int val, int lane) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
+    return v;
+}
+
+template <bool PK>
+__device__ __forceinline__ void far_one_query(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q, int k,
+                                              int psplit, int need, unsigned long long* slot) {
+    const int lane = threadIdx.x & 63;
+    FarQ A;
+    far_begin(A, bx, q, need, k);
+    while (A.m0 | A.m1) {
+        const int r = far_next_patch(A, psplit);
+        const int pos = s_kd[r * ICP_SUB + lane];
+        far_take<PK>(A, s_tpl[pos], pos);
+    }
+    far_end(A, q, k, slot);
+}
+
+template <bool PK>
+__device__ __forceinline__ void search_pairs(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q,
+                                             unsigned long long todo, int psplit, int need, unsigned long long* slots, int* stat_acc = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lanemask_lt();
+#ifdef CD_TIMERS
+    long long tf_[3] = {0, 0, 0}, tfl_ = clock64();
+    unsigned nfq_ = 0, nfp_ = 0;
+#define CD_FARPH(n) { const long long t_ = clock64(); tf_[n] += t_ - tfl_; tfl_ = t_; }
+#else
+#define CD_FARPH(n)
+#endif
+    while (todo) {
+        // ---- P1: box tests of up to FAR_CHUNK queries; their surviving patches become pairs in the lanes of vpair
+        unsigned long long chunk = 0ull;
+        int vpair = 0, np = 0, nq = 0;
+        while (todo && nq < FAR_CHUNK) {
+            const int k = __ffsll((long long)todo) - 1;
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+            const int nd = __builtin_amdgcn_readlane(need, k);
+            unsigned long long m0 = 0ull, m1 = 0ull;
+            if (nd & 1) m0 = ballot64(box_lb(bx.L0, bx.H0, x, y, z) <= best);
+            if (nd & 2) m1 = ballot64(box_lb(bx.L1, bx.H1, x, y, z) <= best);
+            const int cnt = __popcll(m0) + __popcll(m1);
+            if (np + cnt > FAR_PAIRS) {
+                if (nq > 0) break;                  // the chunk is full: this query opens the next one
+                todo &= todo - 1;                   // more patches than a chunk holds: the one-query loop
+                far_one_query<PK>(s_tpl, s_kd, bx, q, k, psplit, need, slots);
+#ifdef CD_STATS
+                if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+                continue;
+            }
+            todo &= todo - 1;
+            chunk |= 1ull << k;
+#ifdef CD_STATS
+            if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+#ifdef CD_ITSTATS
+            if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += cnt; }
+#endif
+            const int tag = (nq << 13) | (k << 7);
+            while (m0) {
+                const int r = __ffsll((long long)m0) - 1;
+                m0 &= m0 - 1;
+                vpair = writelane_i32(vpair, tag | r, np);
+                ++np;
+            }
+            while (m1) {
+                const int r = psplit + __ffsll((long long)m1) - 1;
+                m1 &= m1 - 1;
+                vpair = writelane_i32(vpair, tag | r, np);
+                ++np;
+            }
+            ++nq;
+        }
+        if (nq == 0) continue;
+        // every query lane of the chunk puts its bound (d2 bound : no index) into its word; LDS operations of one wave execute
+        // in program order, so the minima below see it
+        const bool mine = (chunk >> lane) & 1ull;
+        const int rank = __popcll(chunk & lt);
+        const unsigned long long bound = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
+        if (mine) __hip_atomic_store(&slots[rank], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        CD_FARPH(0)
+#ifdef CD_TIMERS
+        nfq_ += (unsigned)nq; nfp_ += (unsigned)np;
+#endif
+        // ---- P2: two pairs per trip (an odd one out is done twice: the minimum does not mind)
+        for (int p = 0; p < np; p += 2) {
+            const int e0 = __builtin_amdgcn_readlane(vpair, p);
+            const int e1 = __builtin_amdgcn_readlane(vpair, p + 1 < np ? p + 1 : p);
+            const int k0 = (e0 >> 7) & 63, k1 = (e1 >> 7) & 63;
+            const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k0));
+            const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k0));
+            const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k0));
+            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane(__float_as_int(q.pbest), k0);
+            const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k1));
+            const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k1));
+            const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k1));
+            const unsigned b1 = (unsigned)__builtin_amdgcn_readlane(__float_as_int(q.pbest), k1);
+            const int pos0 = s_kd[(e0 & 127) * ICP_SUB + lane];
+            const int pos1 = s_kd[(e1 & 127) * ICP_SUB + lane];
+            const float4 t0 = s_tpl[pos0];
+            const float4 t1 = s_tpl[pos1];
+            const float d0 = dist2(x0, y0, z0, t0.x, t0.y, PK ? t0.w : t0.z);   // (PK images are stored (x, y, key word, z))
+            const float d1 = dist2(x1, y1, z1, t1.x, t1.y, PK ? t1.w : t1.z);
+            const unsigned long long key0 = ((unsigned long long)__float_as_uint(d0) << 32) | (PK ? (unsigned)__float_as_int(t0.z) : (((unsigned)__float_as_int(t0.w) << 13) | (unsigned)pos0));
+            const unsigned long long key1 = ((unsigned long long)__float_as_uint(d1) << 32) | (PK ? (unsigned)__float_as_int(t1.z) : (((unsigned)__float_as_int(t1.w) << 13) | (unsigned)pos1));
+            if (key0 < (((unsigned long long)b0 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e0 >> 13], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (key1 < (((unsigned long long)b1 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e1 >> 13], key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        CD_FARPH(1)
+        // ---- P3: the query lanes read their words back
+        if (mine) {
+            const unsigned long long res = __hip_atomic_load(&slots[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const unsigned lo = (unsigned)res;
+            if (lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(res >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
+        }
+        CD_FARPH(2)
+    }
+#ifdef CD_TIMERS
+    if (lane == 0 && (nfq_ | nfp_)) {   // cycles in P1 / P2 / P3, far queries, pairs (slots 0..4 are free in a CD_TIMERS build)
+        atomicAdd(&g_icp_stats[0], (unsigned long long)tf_[0]); atomicAdd(&g_icp_stats[1], (unsigned long long)tf_[1]);
+        atomicAdd(&g_icp_stats[2], (unsigned long long)tf_[2]); atomicAdd(&g_icp_stats[3], (unsigned long long)nfq_);
+        atomicAdd(&g_icp_stats[4], (unsigned long long)nfp_);
+    }
+#endif
+#undef CD_FARPH
+}
 
 // ---------------------------------------------------------------------------------------
 // Wave-per-query search over a template that does NOT fit LDS (more than ICP_TPL_LDS points; up to 65535): the points stay in
@@ -1544,7 +1696,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[BIG ? 1 : ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
-    __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
+    __shared__ unsigned long long s_far[ICPT_WAVES * FAR_CHUNK];   // FAR_CHUNK words per wave: the running minima of the far queries it is on
     __shared__ float4 s_plo[BIG ? ICP_BIG_PATCHES : 1], s_phi[BIG ? ICP_BIG_PATCHES : 1];   // BIG: boxes of all k-d patches
     constexpr int KSH = BIG ? 16 : 13;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1709,7 +1861,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #endif
                     CD_PHASE(2)
                     if constexpr (BIG) {
-                        search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave]);
+                        search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave * FAR_CHUNK]);
                     } else {
                     // which halves of the template can hold a point within this lane's bound (all lanes at once)
                     const float4 hl0 = make_float4(g.half_lo[0][0], g.half_lo[0][1], g.half_lo[0][2], 0.f), hh0 = make_float4(g.half_hi[0][0], g.half_hi[0][1], g.half_hi[0][2], 0.f);
@@ -1717,13 +1869,17 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave], stat_acc);
+                    search_pairs<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK], stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave]);
+#ifndef CD_FAR_PAIRS
+                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
+#else
+                    search_pairs<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
+#endif
 #endif
                     }
                     CD_PHASE(4)

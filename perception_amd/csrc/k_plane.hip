@@ -300,10 +300,10 @@ __global__ void __launch_bounds__(BLOCK) k_mark_indices(const int* __restrict__ 
 }
 // positions i with flag[i] == 0, ascending (ordered compaction: ballots + chained scan over the tiles)
 __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict__ flag, int n, int* __restrict__ state,
-                                                           FrameState* __restrict__ fs, int* __restrict__ out) {
+                                                           FrameState* __restrict__ fs, int* __restrict__ out, int* __restrict__ ticket) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
-    __shared__ int s_excl;
-    const int tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __shared__ int s_excl, s_ticket;
+    const int tile = take_ticket(ticket, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;
@@ -363,8 +363,8 @@ void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag) {
     if (m > 0) hipLaunchKernelGGL(k_mark_indices, dim3((m + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, idx, m, n, flag);
 }
-void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out) {
-    hipLaunchKernelGGL(k_select_unmarked, dim3((n + TILE - 1) / TILE), dim3(BLOCK), 0, s, flag, n, state, fs, out);
+void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out, int* ticket) {
+    hipLaunchKernelGGL(k_select_unmarked, dim3((n + TILE - 1) / TILE), dim3(BLOCK), 0, s, flag, n, state, fs, out, ticket);
 }
 void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out) {
     const size_t tot = (size_t)m * words;

@@ -98,15 +98,17 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
                                                          int T, int Tact, int pass, FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ ghist, int* __restrict__ state,
-                                                         KeyPack kp, int use_runs) {
+                                                         KeyPack kp, int use_runs, int* __restrict__ ticket) {
+    __shared__ int s_ticket;
     __shared__ unsigned short s_wh[SORT_WAVES][RADIX];   // per-wave bin counts, then the wave's offset inside the bin
     __shared__ uint32_t s_goff[RADIX];                   // where the tile's part of each bin starts in the frame
     __shared__ uint32_t s_bstart[RADIX];                 // where each bin starts inside the tile
     __shared__ uint32_t s_k[SORT_TILE], s_v[SORT_TILE];  // the tile, ordered by bin (64 KiB)
     __shared__ uint32_t s_ws[RADIX / WAVE], s_gs[RADIX / WAVE];
-    // workgroup b is tile b / F of frame b % F (see k_crop_fused): a tile's predecessors in the chained scan are long done
+    // ticket b is tile b / F of frame b % F (see k_crop_fused): a tile's predecessors in the chained scan are long done
     const int F = gridDim.x / Tact, shift = pass * RADIX_BITS;
-    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = take_ticket(ticket, &s_ticket);
+    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = use_runs ? fs[f].n_runs : fs[f].n_c;   // (runs: the elements are k_voxel_runs' (voxel index, start | length) pairs)
     if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -220,7 +222,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
 // absolute coordinate fields of k_crop_fused; the first pass writes voxel indices.  Returns the index of the buffers
 // that hold the sorted keys / the permutation, or -1 when the scan state could not be zeroed.
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
-                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp) {
+                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp, int* ticket) {
     if (npass <= 0) return 0;
     // (a failure is also left in hipGetLastError, which the caller's LAUNCH() reads; -1 makes it explicit)
     if (hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s) != hipSuccess) return -1;
@@ -230,7 +232,7 @@ int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val
     int cur = 0;
     for (int pass = 0; pass < npass; ++pass) {
         hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], pass ? val[cur] : nullptr, key[cur ^ 1],
-                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 0);
+                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 0, ticket);
         kp.enabled = 0;   // later passes read voxel indices
         cur ^= 1;
     }
@@ -250,12 +252,13 @@ constexpr int RUN_SHIFT = 20;   // start < 2^20 (CD_MAX_POINTS), length <= 64
 __global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __restrict__ kin, int N, int T, int Tact, int npass,
                                                            FrameState* __restrict__ fs, uint32_t* __restrict__ ghist,
                                                            int* __restrict__ state, uint32_t* __restrict__ kout,
-                                                           uint32_t* __restrict__ vout, KeyPack kp) {
+                                                           uint32_t* __restrict__ vout, KeyPack kp, int* __restrict__ ticket) {
     __shared__ uint32_t s_h[SORT_MAX_PASSES][RADIX];
     __shared__ int s_cnt[SORT_WAVES];
-    __shared__ int s_out0;
+    __shared__ int s_out0, s_ticket;
     const int F = gridDim.x / Tact;
-    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = take_ticket(ticket, &s_ticket);
+    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * SORT_TILE >= n) return;
     for (int q = threadIdx.x; q < SORT_MAX_PASSES * RADIX; q += SORT_BLOCK) (&s_h[0][0])[q] = 0;
@@ -329,18 +332,18 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __res
 // there.  `tile_state` [F][T] (zeroed here) carries the chained scan of the run counts.  Returns the index of the buffers that
 // hold the sorted run keys / payloads, or -1 when a scan state could not be zeroed.
 int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int T, int Tact, int npass,
-                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp) {
+                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp, int* ticket) {
     if (npass <= 0) return 0;
     if (hipMemsetAsync(ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES * RADIX, s) != hipSuccess) return -1;
     if (hipMemsetAsync(state, 0, sizeof(int) * (size_t)npass * F * Tact * RADIX, s) != hipSuccess) return -1;
     if (hipMemsetAsync(tile_state, 0, sizeof(int) * (size_t)F * T, s) != hipSuccess) return -1;
     hipLaunchKernelGGL(k_voxel_runs, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[0], N, T, Tact, npass, fs, ghist, tile_state, key[1],
-                       val[1], kp);
+                       val[1], kp, ticket);
     kp.enabled = 0;
     int cur = 1;
     for (int pass = 0; pass < npass; ++pass) {
         hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], val[cur], key[cur ^ 1], val[cur ^ 1], N,
-                           Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 1);
+                           Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 1, ticket);
         cur ^= 1;
     }
     return cur;

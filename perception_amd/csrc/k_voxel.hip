@@ -207,19 +207,21 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
 
 // ---- single pass: crop + ordered compaction + min/max + absolute voxel coordinates -------
 // One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from chained_scan().
-// Workgroup b is tile b / F of frame b % F: the tiles in flight at any time are a few per frame, so a tile's predecessors
-// are usually long done and its look-back ends at the first word; a scan that gives up sends the batch to the two-pass path.
+// The workgroup with ticket b (take_ticket, common.hpp) is tile b / F of frame b % F: the tiles in flight at any time are a
+// few per frame, so a tile's predecessors are usually long done and its look-back ends at the first word; a scan that gives
+// up (it cannot: the guard of chained_scan) sends the batch to the two-pass path.
 __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ in, size_t stride, int N, int pitch,
                                                       int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
                                                       FrameState* __restrict__ fs, int* __restrict__ state,
                                                       float4* __restrict__ cpt,
-                                                      uint32_t* __restrict__ keys) {
+                                                      uint32_t* __restrict__ keys, int* __restrict__ ticket) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
-    __shared__ int s_excl;
+    __shared__ int s_excl, s_ticket;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int F = gridDim.x / Tin;
-    const int f = blockIdx.x % F, tile = blockIdx.x / F;
+    const int b = take_ticket(ticket, &s_ticket);
+    const int f = b % F, tile = b / F;
     const size_t fbase = (size_t)f * N;        // input records
     const size_t obase = (size_t)f * pitch;    // internal arrays
     const int base = tile * TILE + w * WAVE_SPAN;
@@ -323,14 +325,15 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
                                                           const uint32_t* __restrict__ vals,
                                                           const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
                                                           FrameState* __restrict__ fs, int* __restrict__ state,
-                                                          float4* __restrict__ vox) {
+                                                          float4* __restrict__ vox, int* __restrict__ ticket) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];     // sorted positions of the voxel heads of this tile, in order
-    __shared__ int s_out0;
-    // workgroup b is tile b / F of frame b % F (see k_crop_fused): the position of a tile's first voxel in the frame's
+    __shared__ int s_out0, s_ticket;
+    // ticket b is tile b / F of frame b % F (see k_crop_fused): the position of a tile's first voxel in the frame's
     // output comes from a chained scan of the tiles' head counts, so the heads are found once (no count pass + scan)
     const int F = gridDim.x / Tact;
-    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = take_ticket(ticket, &s_ticket);
+    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -410,12 +413,13 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                                                                const uint32_t* __restrict__ vals,
                                                                const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
                                                                FrameState* __restrict__ fs, int* __restrict__ state,
-                                                               float4* __restrict__ vox) {
+                                                               float4* __restrict__ vox, int* __restrict__ ticket) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];
-    __shared__ int s_out0;
+    __shared__ int s_out0, s_ticket;
     const int F = gridDim.x / Tact;
-    const int f = blockIdx.x % F, tile = blockIdx.x / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int b = take_ticket(ticket, &s_ticket);
+    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_runs;
     if (tile * TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -529,18 +533,18 @@ void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, in
                        fs, tile_off, cpt, keys);
 }
 void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
-                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys) {
+                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket) {
     const int Tin = (N + TILE - 1) / TILE;
     hipLaunchKernelGGL(k_crop_fused, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
-                       leaf, kp, fs, state, cpt, keys);
+                       leaf, kp, fs, state, cpt, keys, ticket);
 }
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox) {
-    hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox);
+                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {
+    hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket);
 }
 void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox) {
-    hipLaunchKernelGGL(k_voxel_centroid_runs, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox);
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {
+    hipLaunchKernelGGL(k_voxel_centroid_runs, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket);
 }
 
 }  // namespace cd

@@ -10,26 +10,26 @@ void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int 
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
 void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf);
 void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
-                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys);
+                       int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket);
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
+                           int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
 void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox);
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
-void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out);
+void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out, int* ticket);
 void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out);
 void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out);
 
 // k_sort.hip : segmented (per frame) stable LSD radix sort of (key, value) pairs, all passes
 constexpr int SORT_MAX_PASSES_HOST = 4;
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
-                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp);
+                      FrameState* fs, uint32_t* ghist, int* state, KeyPack kp, int* ticket);
 // the same sort over RUNS of equal voxel index (k_voxel_runs: 2-3 x fewer elements on organised clouds); tile_state: [F][T] ints
 int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int T, int Tact, int npass,
-                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp);
+                           FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp, int* ticket);
 
 // k_plane.hip
 void launch_ransac_sample(hipStream_t s, const float4* vox, int N, int F, FrameState* fs, const int* rnd_table,

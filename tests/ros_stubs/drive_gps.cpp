@@ -32,6 +32,14 @@ int main(int argc, char** argv) {
         std::memcpy(&msg->data[(size_t)i * 32], &raw[4 * (size_t)i], 12);
         std::memcpy(&msg->data[(size_t)i * 32 + 16], &raw[4 * (size_t)i + 3], 4);
     }
+    // GPS_DRIVE_BAD=float64 | offset | step: a field table the device code cannot take (x,y,z must be FLOAT32 at 0/4/8 in
+    // records of whole words) - the node must refuse it (ROS_ERROR, nothing published), not publish garbage
+    if (const char* bad = std::getenv("GPS_DRIVE_BAD")) {
+        const std::string b = bad;
+        if (b == "float64") msg->fields[1].datatype = sensor_msgs::PointField::FLOAT64;
+        else if (b == "offset") msg->fields[2].offset = 12;
+        else if (b == "step") msg->point_step = 30;
+    }
     ros::stub::set("voxel_size", argc > 3 ? std::atof(argv[3]) : 0.005);
     ros::stub::set("distance_threshold", argc > 4 ? std::atof(argv[4]) : 0.015);
     ros::stub::set("invert", true);

@@ -54,6 +54,19 @@ def test_gps_node_publishes_the_input_layout(O, tmp_path):
     assert np.array_equal(coeff.view(np.uint32), c1.view(np.uint32))
 
 
+@pytest.mark.parametrize("bad", ["float64", "offset", "step"])
+def test_gps_node_refuses_layouts_the_device_code_cannot_read(bad, tmp_path):
+    """x,y,z as FLOAT32 at byte offsets 0/4/8 in records of whole 4-byte words is what cd_ground_plane reads and writes; a
+    PointCloud2 that says otherwise (a FLOAT64 field, z at another offset, a 30-byte point_step) gets ROS_ERROR and no
+    publication - never a cloud of reinterpreted bytes under the input's field table."""
+    subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
+    fin, fout = str(tmp_path / "frame.bin"), str(tmp_path / "out.bin")
+    synth.frame(2).astype(np.float32).tofile(fin)
+    r = subprocess.run([os.path.join(CPP, "gps_shim_driver"), fin, fout, "0.005", "0.015"], env=dict(os.environ, GPS_DRIVE_BAD=bad),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3 and "nothing published" in r.stderr and not os.path.exists(fout)
+
+
 def _read_cloud_dump(path):
     """a PointCloud2 as tests/ros_stubs/drive_opd.cpp dumps it"""
     blob = open(path, "rb").read()

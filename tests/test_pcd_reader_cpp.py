@@ -168,3 +168,25 @@ def test_errors_are_reported(tool, tmp_path):
         assert got is None and r.returncode == 1 and msg in r.stderr
     got, r = _load(tool, tmp_path / "missing.pcd", tmp_path)
     assert got is None and "cannot open" in r.stderr
+
+
+def test_hostile_headers_return_minus_one_instead_of_throwing(tool, tmp_path):
+    """The header is not trusted: point counts far beyond what the file holds, WIDTH x HEIGHT that overflows,
+    a binary_compressed block that claims 4 GiB - every one is the documented -1 (exit code 1 of pcd_tool, a message on
+    stderr), decided before anything is allocated; none ends in bad_alloc / length_error (which would abort: exit code < 0)."""
+    p = tmp_path / "h.pcd"
+    xyz = (["x", "y", "z"], [4, 4, 4], list("FFF"), [1, 1, 1])
+    cases = (
+        (_header(*xyz, 2 ** 40, "binary") + b"\0" * 24, "out of range"),
+        (_header(*xyz, 2 ** 30, "binary") + b"\0" * 24, "ends early"),
+        (_header(*xyz, 2 ** 30, "ascii") + b"1 2 3\n", "ends early"),
+        (_header(*xyz, 0, "ascii", width=2 ** 31, height=2 ** 31, points=False) + b"1 2 3\n", "ends early"),
+        (_header(*xyz, 0, "ascii", width=2 ** 62, height=4, points=False) + b"1 2 3\n", "out of range"),
+        (_header(*xyz, (2 ** 32 - 4) // 12, "binary_compressed") + struct.pack("<II", 2 ** 32 - 8, 2 ** 32 - 4) + b"\0" * 16, "ends early"),
+        (_header(*xyz, 2 ** 20, "binary_compressed") + struct.pack("<II", 3, 12 * 2 ** 20) + b"\xe0\x01\x02", "malformed"),
+        (_header(["x", "y", "z"], [2 ** 30, 4, 4], list("FFF"), [1, 1, 1], 4, "binary") + b"\0" * 64, "bad record size"),
+    )
+    for blob, msg in cases:
+        p.write_bytes(blob)
+        got, r = _load(tool, p, tmp_path)
+        assert got is None and r.returncode == 1 and msg in r.stderr, (msg, r.returncode, r.stderr[-300:])
