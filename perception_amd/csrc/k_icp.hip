@@ -813,6 +813,97 @@ __device__ __forceinline__ void search_pairs(const float4* s_tpl, const unsigned
 #undef CD_FARPH
 }
 
+// The pair search with NO scalar round trips in its inner loops (round 4, second form).  The first form above keeps the pair
+// list in a vector register and reads it, and the queries' coordinates, back with v_readlane: every pair then starts with a
+// chain VALU -> SGPR -> SALU -> VALU -> LDS, and the timers showed ~360 cycles per pair and ~780 per query in P1 for ~55
+// instructions: it is those hops between the vector and the scalar side, not the LDS round trips alone, that a far query's
+// time consists of.  Here
+//   P1  files the pairs lane-parallel: the lanes whose patch box passed write (slot, query lane, patch) as 16-bit entries at
+//       list[np + mbcnt(mask)] - one ds_write_b16 under the ballot's own mask, no scalar loop over the set bits;
+//   P2  is vector-only: the entry is a broadcast LDS read, the query's coordinates come through ds_bpermute (the LDS crossbar,
+//       no memory), addresses are vector arithmetic; two pairs per trip, all loads of both in flight together;
+//   P3  as before.
+// LDS per wave: FAR_CHUNK 64-bit words + FAR_LIST 16-bit entries (192 bytes).
+constexpr int FAR_LIST = 32;    // pairs per chunk (second form)
+template <bool PK>
+__device__ __forceinline__ void search_pairs_v(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q,
+                                               unsigned long long todo, int psplit, int need, unsigned long long* slots,
+                                               unsigned short* list, int* stat_acc = nullptr) {
+    const int lane = threadIdx.x & 63;
+    const unsigned long long lt = lanemask_lt();
+    while (todo) {
+        unsigned long long chunk = 0ull;
+        int np = 0, nq = 0;
+        while (todo && nq < FAR_CHUNK) {
+            const int k = __ffsll((long long)todo) - 1;
+            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
+            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
+            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
+            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
+            const int nd = __builtin_amdgcn_readlane(need, k);
+            unsigned long long m0 = 0ull, m1 = 0ull;
+            if (nd & 1) m0 = ballot64(box_lb(bx.L0, bx.H0, x, y, z) <= best);
+            if (nd & 2) m1 = ballot64(box_lb(bx.L1, bx.H1, x, y, z) <= best);
+            const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);
+            if (np + cnt > FAR_LIST) {
+                if (nq > 0) break;
+                todo &= todo - 1;
+                far_one_query<PK>(s_tpl, s_kd, bx, q, k, psplit, need, slots);
+#ifdef CD_STATS
+                if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+                continue;
+            }
+            todo &= todo - 1;
+            chunk |= 1ull << k;
+#ifdef CD_STATS
+            if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
+#endif
+#ifdef CD_ITSTATS
+            if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += cnt; }
+#endif
+            const int tag = (nq << 13) | (k << 7);
+            if ((m0 >> lane) & 1ull) list[np + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)(tag | lane);
+            if ((m1 >> lane) & 1ull) list[np + c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)(tag | (psplit + lane));
+            np += cnt;
+            ++nq;
+        }
+        if (nq == 0) continue;
+        const bool mine = (chunk >> lane) & 1ull;
+        const int rank = __popcll(chunk & lt);
+        const unsigned long long bound = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
+        if (mine) __hip_atomic_store(&slots[rank], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        for (int p = 0; p < np; p += 2) {
+            const int e0 = list[p];
+            const int e1 = list[p + 1 < np ? p + 1 : p];
+            const int a0 = (e0 >> 5) & 0xfc, a1 = (e1 >> 5) & 0xfc;   // byte address of the query lane's dword for ds_bpermute
+            const int pos0 = s_kd[(e0 & 127) * ICP_SUB + lane];
+            const int pos1 = s_kd[(e1 & 127) * ICP_SUB + lane];
+            const float x0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.px)));
+            const float y0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.py)));
+            const float z0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.pz)));
+            const unsigned b0 = (unsigned)__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.pbest));
+            const float x1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.px)));
+            const float y1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.py)));
+            const float z1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.pz)));
+            const unsigned b1 = (unsigned)__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.pbest));
+            const float4 t0 = s_tpl[pos0];
+            const float4 t1 = s_tpl[pos1];
+            const float d0 = dist2(x0, y0, z0, t0.x, t0.y, PK ? t0.w : t0.z);   // (PK images are stored (x, y, key word, z))
+            const float d1 = dist2(x1, y1, z1, t1.x, t1.y, PK ? t1.w : t1.z);
+            const unsigned long long key0 = ((unsigned long long)__float_as_uint(d0) << 32) | (PK ? (unsigned)__float_as_int(t0.z) : (((unsigned)__float_as_int(t0.w) << 13) | (unsigned)pos0));
+            const unsigned long long key1 = ((unsigned long long)__float_as_uint(d1) << 32) | (PK ? (unsigned)__float_as_int(t1.z) : (((unsigned)__float_as_int(t1.w) << 13) | (unsigned)pos1));
+            if (key0 < (((unsigned long long)b0 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e0 >> 13], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (key1 < (((unsigned long long)b1 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e1 >> 13], key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (mine) {
+            const unsigned long long res = __hip_atomic_load(&slots[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            const unsigned lo = (unsigned)res;
+            if (lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(res >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // Wave-per-query search over a template that does NOT fit LDS (more than ICP_TPL_LDS points; up to 65535): the points stay in
 // global memory (a few hundred KiB: L2-resident) in k-d patch order, so a patch is ONE coalesced 1 KiB read; the patch boxes
@@ -1697,6 +1788,9 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[BIG ? 1 : ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     __shared__ unsigned long long s_far[ICPT_WAVES * FAR_CHUNK];   // FAR_CHUNK words per wave: the running minima of the far queries it is on
+#if defined(CD_FAR_PAIRS) && CD_FAR_PAIRS == 2
+    __shared__ unsigned short s_flist[BIG ? 1 : ICPT_WAVES * FAR_LIST];   // the wave's (slot, query, patch) pairs
+#endif
     __shared__ float4 s_plo[BIG ? ICP_BIG_PATCHES : 1], s_phi[BIG ? ICP_BIG_PATCHES : 1];   // BIG: boxes of all k-d patches
     constexpr int KSH = BIG ? 16 : 13;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1877,6 +1971,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #else
 #ifndef CD_FAR_PAIRS
                     search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
+#elif CD_FAR_PAIRS == 2
+                    search_pairs_v<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK], &s_flist[wave * FAR_LIST]);
 #else
                     search_pairs<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
 #endif
