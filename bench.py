@@ -21,7 +21,7 @@ import time
 # config 5's six batches have two low-priority ICP streams each, and with 8 queues four of those twelve streams share
 # one (rocprofv3 kernel trace: a batch's k_icp_pipe starts when another batch's k_icp_pipe_big ends) - 16 there.  Must be
 # set before the HIP runtime initialises: main() does it once the arguments are known.
-DEFAULT_HW_QUEUES = {3: "8", 5: "16"}
+DEFAULT_HW_QUEUES = {3: "16", 5: "16"}   # (config 3 measures the same with 8 and with 16: profiles/r03_ab_hwq.txt; its config-5 leg wants 16)
 
 import numpy as np
 
@@ -33,10 +33,12 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak
 # Counter files of the current round under profiles/ (written by tools/profile_round.sh and tools/probe_icp_work.py on the
 # GPU box, copied into profiles/ and committed); the previous round's are the fallback until this round's exist.
-PMC_TRAFFIC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json")   # HBM bytes per dispatch: separate --pmc FETCH_SIZE / WRITE_SIZE passes
-PMC_SQ_FILES = ("r03_pmc_icp.txt", "r02_pmc_icp.txt")                   # SQ counters per kernel (four separate --pmc passes)
-ICP_WORK_FILES = ("r03_icp_work.json",)                                 # executed distance tests of the dominant kernel (-DCD_STATS build)
+PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")   # HBM bytes per dispatch: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILES = ("r04_pmc_icp.txt", "r03_pmc_icp.txt", "r02_pmc_icp.txt")                   # SQ counters per kernel (separate --pmc passes)
+ICP_WORK_FILES = ("r04_icp_work.json", "r03_icp_work.json")                                # executed distance tests of the dominant kernel (-DCD_STATS build)
+VALU_CALIBRATION_FILES = ("r04_valu_calibration.json",)   # what the SQ counters read on a SATURATED vector pipe (tools/valu_calib.hip, same launch shape)
 WAVES_PER_SIMD_ICP = 4          # k_icp_pipe: one 1024-thread workgroup per CU = 16 waves = 4 per SIMD
+SIMDS = 1024                    # 256 CUs x 4
 
 
 def _first_profile(names):
@@ -229,6 +231,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true", help="skip the single-frame latency measurement (BASELINE config 2; runs after the timed region)")
     ap.add_argument("--no-verify", action="store_true", help="skip the self-check of the timed path's records (runs after the timed region)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs of the default N = 1 line (config 5, the 21 400-point template, host-fed): they run after the timed region and are never part of `value`")
+    ap.add_argument("--legs-config5-frames", type=int, default=64, help="frames per batch of the config-5 leg")
     ap.add_argument("--guess", choices=("none", "sne", "track"), default="none",
                     help="after the headline measurement, a separately labelled leg with per-frame initial guesses (opt-in ICP guess; "
                          "reported under guess_leg, never part of value).  sne: the inverse of the cuboid frame of "
@@ -267,6 +271,10 @@ def main():
     os.environ.setdefault("GPU_MAX_HW_QUEUES", DEFAULT_HW_QUEUES[args.config])
     # host-side inputs first (fork pool must not follow GPU init)
     frames = make_frames(rank * F, F, args.config)
+    # the extra legs of the default N = 1 line (after the timed region, never part of `value`): config 5 and the reference's
+    # 21 400-point template, driver-visible, and the host-fed rate (item 5)
+    legs = world == 1 and args.config == 3 and not args.no_legs
+    frames_c5 = make_frames(0, args.legs_config5_frames, 5) if legs else None
 
     import torch
     import torch.distributed as dist
@@ -502,6 +510,91 @@ def main():
             ok = bool(tv.item())
         verified = ok
 
+    # ---- extra legs of the default N = 1 line: after the timed region, separately labelled, never part of `value` ----------
+    legs_out = {}
+    if legs:
+        def pump(pl, ptr, n_pts, n_fr, pr, k, host=False):
+            """k batches through pipeline `pl`, all waited for; returns (records of the last one, seconds)"""
+            a = time.perf_counter()
+            futs = [pl.submit(ptr, 16, n_pts, n_fr, pr, host=host) for _ in range(k)]
+            rec_last = [f.result()[0] for f in futs][-1]
+            torch.cuda.synchronize()
+            return rec_last, time.perf_counter() - a
+
+        fence()
+        # (1) host-fed: the frames come from HOST memory through cd_process_batch (the upload is part of every call, on the
+        # context's own stream, so it overlaps the other contexts' kernels) - what a ROS callback has (gps.cpp:43-49).  Pinned
+        # memory for the PCIe rate; pageable (what roscpp hands over) beside it.
+        try:
+            mb = frames.nbytes / 1e6
+            pinned = torch.from_numpy(frames).pin_memory()
+            pump(pipe, pinned.data_ptr(), N, F, prm, M, host=True)                       # staging buffers, first touch
+            hrec, hs = pump(pipe, pinned.data_ptr(), N, F, prm, 4 * M, host=True)
+            pump(pipe, frames.ctypes.data, N, F, prm, 2, host=True)
+            prec, ps = pump(pipe, frames.ctypes.data, N, F, prm, M, host=True)
+            same = bool(np.array_equal(hrec, allrec[rank * F:(rank + 1) * F]) and np.array_equal(prec, hrec))
+            legs_out["host_fed"] = {
+                "frames_per_s": F * 4 * M / hs, "GBps": mb * 4 * M / hs / 1e3, "frac_of_63_GBps_pcie": mb * 4 * M / hs / 1e3 / 63.0,
+                "batches": 4 * M, "batches_in_flight": M, "pageable_frames_per_s": F * M / ps, "pageable_GBps": mb * M / ps / 1e3,
+                "records_identical_to_the_timed_path": same,
+                "note": "cd_process_batch from host memory: %.1f MB per batch over PCIe Gen5 x16 (63 GB/s spec), pinned source, the H2D copy of a "
+                        "batch on its context's stream beside the other contexts' kernels; pageable = the same from ordinary "
+                        "memory (the runtime stages it through its own pinned buffers); outside `value`" % mb}
+            del pinned
+        except Exception as e:   # a leg must not take the headline down
+            legs_out["host_fed"] = {"error": repr(e)}
+        # (2) the reference's own 21 400-point six-face template (template_cuboid_L200_W100_H75.pcd: not LDS-resident ->
+        # k_icp_pipe_big), same 256 frames, strictly serial
+        try:
+            from perception_amd import pcd
+            big = pcd.read_xyz(os.path.join(ROOT, "tests", "golden", "template_cuboid_L200_W100_H75.pcd")).astype(np.float32)
+            cb = capi.Context(max_points=N, max_frames=F, device_id=local_rank)
+            cb.set_template(0, big)
+            resb = (capi.CdFrameResult * F)()
+            tb = []
+            for _ in range(4):
+                torch.cuda.synchronize()
+                a = time.perf_counter()
+                cb.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=resb)
+                tb.append((time.perf_counter() - a) * 1e3)
+            tmb = cb.timing()
+            itb = [resb[f].clusters[k].iterations for f in range(F) for k in range(min(resb[f].n_clusters, capi.CD_MAX_CLUSTERS_PER_FRAME))]
+            legs_out["big_template_ms"] = {"batch_ms": float(min(tb[1:])), "icp_kernel_ms": float(tmb.icp_kernel_ms), "frames": F,
+                                           "template_points": int(len(big)), "clusters": len(itb), "mean_iterations": float(np.mean(itb)) if itb else 0.0,
+                                           "icp_regime": {"slots": tmb.icp_regime >> 16, "workgroups": tmb.icp_regime & 0xffff},
+                                           "note": "one batch of the same frames against the reference's 21 400-point template, one context, idle GPU"}
+            cb.close()
+        except Exception as e:
+            legs_out["big_template_ms"] = {"error": repr(e)}
+        # (3) BASELINE config 5: 1 M-point frames, five cuboids, five templates, every cluster against every template
+        try:
+            from perception_amd import synth
+            F5, M5, K5 = len(frames_c5), 4, 10
+            tpl5 = {k: templates.template_xyz32(L, W, H, dd) for k, (L, W, H, dd) in enumerate(synth.CONFIG5_DIMS)}
+            prm5 = capi.default_params()
+            prm5.rgb_offset = 12
+            prm5.template_slot = -1
+            prm5.crop_x_min, prm5.crop_x_max = -synth.CONFIG5_CROP_X, synth.CONFIG5_CROP_X
+            prm5.crop_z_max = prm5.crop2_z_max = 1.2
+            N5 = frames_c5.shape[1]
+            pipe5 = batch.BatchPipeline(N5, F5, tpl5, device_id=local_rank, inflight=M5)
+            d5 = torch.from_numpy(frames_c5).to(dev)
+            torch.cuda.synchronize()
+            pump(pipe5, d5.data_ptr(), N5, F5, prm5, 2)
+            rec5, s5 = pump(pipe5, d5.data_ptr(), N5, F5, prm5, K5)
+            r5 = (capi.CdFrameResult * F5)()
+            pipe5.contexts[0].process_batch_device(d5.data_ptr(), 16, N5, F5, prm5, results=r5)      # strictly serial pass
+            ok5 = bool(np.array_equal(capi.results_to_array(r5)[:F5], rec5))
+            legs_out["config5"] = {"frames_per_s": F5 * K5 / s5, "ms_per_step": s5 / K5 * 1e3, "frames_per_batch": F5, "steps": K5,
+                                   "batches_in_flight": M5, "verified": ok5, "points_per_frame": int(N5),
+                                   "templates": [len(t) for t in tpl5.values()],
+                                   "note": "BASELINE config 5 on one GPU after the headline measurement: every cluster against every template, "
+                                           "lowest fitness wins; verified = the last pipelined batch's records equal a strictly serial pass"}
+            pipe5.close()
+            del d5
+        except Exception as e:
+            legs_out["config5"] = {"error": repr(e)}
+
     exit_code = 0
     if rank == 0:
         recs = capi.results_from_array(allrec)
@@ -528,19 +621,58 @@ def main():
                 traffic = pmc["kernels"][icp_kernel]["hbm_bytes_per_dispatch"]
         except (OSError, KeyError, ValueError, TypeError):
             pass
-        # What bounds the dominant kernel, from its SQ counters: vector-ALU issue when the waves of a SIMD together keep
-        # its issue port busy most of the time (SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES is per wave; x waves per SIMD).
+        # With M batches in flight the persistent launches of several batches share the chip: the per-launch duration of the
+        # timed region is then longer than the kernel's cost (8.89 ms per launch against 5.48 ms per step).  The
+        # headline achieved / frac therefore use the duration of ONE launch on an otherwise idle GPU - the strictly serial pass of
+        # the self-check after the timed region, HIP events on the context's stream like the timed launches, <= ms_per_step -
+        # and the overlapped figure is the secondary one (`in_flight`).
+        overlap = (icp_ms * 1e-3) / elapsed if elapsed > 0 else None
+        in_flight = {"avg_launch_ms": avg_launch_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "launches_in_flight": overlap,
+                     "note": "the same kernel's launches inside the timed region (HIP events): `launches_in_flight` of them share the chip at any "
+                             "time, so this duration is queueing plus work"}
+        excl_ms = None
+        regime = None
+        if serial_t is not None and serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0:
+            excl_ms = float(serial_t.icp_kernel_ms)
+            regime = {"slots": serial_t.icp_regime >> 16, "workgroups": serial_t.icp_regime & 0xffff}
+        head_ms = excl_ms if excl_ms is not None else avg_launch_ms
+        head_achieved = per_launch_bytes / (head_ms * 1e-3) / 1e9
+        timed_regime = None
+        if timings and timings[-1].icp_regime:
+            timed_regime = {"slots": timings[-1].icp_regime >> 16, "workgroups": timings[-1].icp_regime & 0xffff}
+        # What bounds the dominant kernel.  Its working set is LDS/L2-resident (traffic = 0.37 x algorithmic bytes), so HBM is not
+        # its roof; the SQ counters (committed, collected by tools/profile_round4.sh on ONE launch alone: the regime of `achieved`)
+        # are read against what the same counters show on a SATURATED vector pipe at the same launch shape
+        # (profiles/r04_valu_calibration.json, tools/valu_calib.hip): both round 3's formula and the first-principles one are
+        # reported, raw and as a fraction of their saturation value.
         sq_file, sq = sq_counters(icp_kernel)
         valu = None
         bound = "hbm"
-        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU") and args.config == 3:
-            issue = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * WAVES_PER_SIMD_ICP
-            valu = {"issue_frac": issue, "counters_file": "profiles/" + sq_file,
-                    "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"],
+        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_INSTS_VALU") and args.config == 3:
+            cname, cpath = _first_profile(VALU_CALIBRATION_FILES)
+            cal = json.load(open(cpath)) if cpath else None
+            wave_cycles = sq["SQ_WAVE_CYCLES"] * 4.0 / (256 * 16)       # quad-cycles summed over 4096 waves -> cycles of one wave's life
+            A = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * WAVES_PER_SIMD_ICP
+            B = sq["SQ_INSTS_VALU"] * 2.0 / (SIMDS * wave_cycles)
+            valu = {"counters_file": "profiles/" + sq_file, "calibration_file": ("profiles/" + cname) if cname else None,
+                    "regime_of_the_counters": "one launch alone (bench.py --steps 1 --warmup 0): 2 slots x 256 workgroups, the regime of roofline.achieved",
+                    "SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"],
                     "waves_per_simd": WAVES_PER_SIMD_ICP,
-                    "salu_per_valu": (sq.get("SQ_INSTS_SALU", 0.0) / sq["SQ_INSTS_VALU"]) if sq.get("SQ_INSTS_VALU") else None,
-                    "wait_any_frac": (sq.get("SQ_WAIT_INST_ANY", 0.0) / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_INST_ANY") else None,
-                    "lds_bank_conflict_frac": (sq.get("SQ_LDS_BANK_CONFLICT", 0.0) / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") else None}
+                    "A_active_over_wave_cycles_x_waves": A, "B_insts_x2_over_simd_cycles": B,
+                    "salu_per_valu": (sq.get("SQ_INSTS_SALU", 0.0) / sq["SQ_INSTS_VALU"]),
+                    "wait_any_frac": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_ANY") else None,
+                    "wait_inst_any_frac": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_INST_ANY") else None,
+                    "active_inst_any_frac": (sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_ACTIVE_INST_ANY") else None}
+            if cal:
+                sat, mix = cal["saturation"], cal["saturation_search_mix"]
+                valu.update({"A_at_saturation": sat["A"], "B_at_saturation": sat["B"],
+                             "pipe_frac": B / sat["B"], "pipe_frac_vs_search_mix": B / mix["B"],
+                             "note": "pipe_frac = B / B_at_saturation = A / A_at_saturation: the share of the saturated f32 vector rate (independent "
+                                     "v_fma_f32, four waves per SIMD) this kernel issues; against a stream of its own instruction mix (LDS reads, 64-bit "
+                                     "key minima) pipe_frac_vs_search_mix.  Round 3 printed A as 'issue_frac 0.86': A reads 2.36, not 1.0, when the "
+                                     "pipe is full"})
+                pf = valu["pipe_frac"]
+                bound = "valu" if pf >= 0.8 else "latency"
             wname, wpath = _first_profile(ICP_WORK_FILES)
             if wpath:
                 try:
@@ -548,26 +680,10 @@ def main():
                     fl = float(w["executed_flops"])
                     valu.update({"work_file": "profiles/" + wname, "executed_pair_tests": w["executed_pair_tests"]["total"],
                                  "flops_per_test": w["flops_per_pair_test"], "executed_flops_per_launch": fl,
-                                 "achieved_tflops": fl / (avg_launch_ms * 1e-3) / 1e12,
-                                 "frac_of_157.3_TFLOPs": fl / (avg_launch_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS,
-                                 "note": "distance and box arithmetic only (8 / 17 flops per test); the rest of the issue slots goes to "
-                                         "key packing, 64-bit compares, address arithmetic, control flow and the fixed-point moments"})
+                                 "achieved_tflops": fl / (head_ms * 1e-3) / 1e12,
+                                 "frac_of_157.3_TFLOPs": fl / (head_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS})
                 except (OSError, KeyError, ValueError):
                     pass
-            if issue >= 0.6:
-                bound = "valu"
-        # With M batches in flight the persistent launches of several batches share the chip: the per-launch duration above is
-        # then longer than the kernel's cost.  Two more figures: how many such launches run at a time on average (sum of their
-        # durations over the wall time), and the duration of ONE launch on an otherwise idle GPU - the serial pass of the
-        # self-check, HIP events on the context's stream like the timed launches.
-        overlap = (icp_ms * 1e-3) / elapsed if elapsed > 0 else None
-        exclusive = None
-        if serial_t is not None and serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0:
-            exclusive = {"avg_launch_ms": serial_t.icp_kernel_ms,
-                         "achieved": per_launch_bytes / (serial_t.icp_kernel_ms * 1e-3) / 1e9,
-                         "frac": per_launch_bytes / (serial_t.icp_kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                         "note": "one launch of the same kernel on the same batch with nothing else on the GPU (the strictly serial "
-                                 "pass of the self-check, after the timed region)"}
         out = {
             "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)",
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -585,17 +701,24 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "batches_in_flight": M,
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
-            "roofline": {"kernel": icp_kernel, "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
-                         "avg_launch_ms": avg_launch_ms, "launches_per_step": icp_launches / args.steps,
+            "roofline": {"kernel": icp_kernel, "bound": bound, "achieved": head_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": head_achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
+                         "traffic_note": "HBM bytes of one launch from the committed counter file (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                         "this workload, gfx950 x2 FETCH correction; counters cannot be collected inside this run)",
+                         "avg_launch_ms": head_ms, "avg_launch_ms_is": "one launch alone on an idle GPU (serial pass after the timed region)" if excl_ms is not None else
+                                                                        "launches of the timed region (no serial pass: --no-verify)",
+                         "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "launches_in_flight": overlap, "exclusive": exclusive,
+                         "regime": regime, "in_flight": in_flight, "in_flight_regime": timed_regime,
                          "valu": valu,
-                         "note": "achieved/peak/frac: algorithmic bytes of the dominant kernel over its HIP-event duration in the timed region against "
-                                 "the HBM peak, as the contract defines them - with several batches in flight `launches_in_flight` of these "
-                                 "launches share the chip at any time, so that duration is longer than the kernel's cost (`exclusive`: one "
-                                 "launch alone); `bound` is what the SQ counters say limits it (valu: f32 vector issue, see roofline.valu - "
-                                 "its working set is LDS/L2-resident), DESIGN.md section 4"},
+                         "note": "achieved/frac: algorithmic bytes of the dominant kernel (SURVEY 8(d): 12 M + 12 N_s (I + 1) per cluster) over the "
+                                 "duration of ONE launch with the GPU to itself, against the HBM peak as the contract defines the block - a duration "
+                                 "that is the kernel's cost (<= ms_per_step); `in_flight` = the same over the launches of the timed region, which "
+                                 "overlap.  `bound`: HBM is not this kernel's roof (traffic < algorithmic bytes: the working set is LDS/L2-resident) "
+                                 "and, measured against a saturated pipe, neither is vector issue (valu.pipe_frac): its waves sit at s_waitcnt / "
+                                 "s_sleep for valu.wait_any_frac of their life - dependent LDS round trips and scalar/vector hand-overs (DESIGN.md "
+                                 "section 4)"},
             "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
                            "note": "exact search by pruning (lane-per-query grid walk for near queries, wave-per-query k-d patch search for far ones): "
@@ -617,6 +740,7 @@ def main():
                                               "cd_ground_plane = ground_plane_segmentation's callback (gps.cpp:43-112) as one call incl. the download of "
                                               "the kept records; host wall clock of the synchronous C-ABI call"} if len(lat_host) > 2 else None),
             "guess_leg": guess_leg,
+            "host_fed": legs_out.get("host_fed"), "big_template_ms": legs_out.get("big_template_ms"), "config5": legs_out.get("config5"),
             "cu_fill_debug": cu_fill,
             "verified": verified,
             "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "

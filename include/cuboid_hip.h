@@ -308,10 +308,13 @@ typedef struct cd_timing {
                                                    * multi-launch loop (same results, tens of ms slower): 0 in a healthy run           */
     int64_t algorithmic_bytes;                    /* B_alg of SURVEY 8(d) for this batch */
     int64_t icp_algorithmic_bytes;                /* the S6 term of B_alg: sum 12*M + 12*N_s*(I_c+1) */
-    int32_t scan_retries;                         /* 1 when this call was redone because a chained scan stalled (several contexts on one
-                                                   * GPU can block each other's ordered compactions; the redo runs with the device to
-                                                   * itself): 0 in a healthy run                                                        */
-    int32_t reserved;
+    int32_t scan_retries;                         /* 1 when this call was redone because a chained scan reported a stall (cannot happen on
+                                                   * its own since the scans take their tile ids from atomic tickets; the redo runs with
+                                                   * the device to itself): 0 in a healthy run                                          */
+    int32_t icp_regime;                           /* launch shape of the whole-cluster ICP kernel of this call: (clusters in flight per
+                                                   * workgroup << 16) | workgroups; 0 = no such launch (sliced driver).  The shape is
+                                                   * chosen from the calls in flight on the device (scheduling only: results do not
+                                                   * depend on it), so a measurement can say which shape it measured                    */
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

@@ -87,13 +87,17 @@ class BatchPipeline:
         self._busy = [None] * self.inflight
         self._pool = ThreadPoolExecutor(self.inflight)
 
-    def _run(self, i, d_ptr, stride, n_points, n_frames, prm):
+    def _run(self, i, d_ptr, stride, n_points, n_frames, prm, host=False):
         cx, res = self.contexts[i], self._results[i]
-        cx.process_batch_device(d_ptr, stride, n_points, n_frames, prm, results=res)
+        if host:    # host-fed: the H2D copy is part of the call, on the context's own stream - it overlaps the other contexts' kernels
+            cx.process_batch_host_ptr(d_ptr, stride, n_points, n_frames, prm, results=res)
+        else:
+            cx.process_batch_device(d_ptr, stride, n_points, n_frames, prm, results=res)
         return capi.results_to_array(res)[:n_frames].copy(), cx.timing()
 
-    def submit(self, d_ptr, stride, n_points, n_frames, prm):
-        """Queue one batch that is already resident in device memory (d_ptr: device pointer of F x N records)."""
+    def submit(self, d_ptr, stride, n_points, n_frames, prm, host=False):
+        """Queue one batch that is already resident in device memory (d_ptr: device pointer of F x N records), or - host=True -
+        one that sits in HOST memory (pinned for full PCIe rate): what a ROS callback has (gps.cpp:43-49)."""
         # a context runs one batch at a time: take a free one, else wait for the first to finish (batches differ in length: a
         # fixed rotation would hold the submission behind the slowest)
         from concurrent.futures import FIRST_COMPLETED, wait
@@ -102,7 +106,7 @@ class BatchPipeline:
             wait(self._busy, return_when=FIRST_COMPLETED)
             free = [j for j in range(self.inflight) if self._busy[j].done()]
         i = free[0]
-        fut = self._pool.submit(self._run, i, d_ptr, stride, n_points, n_frames, prm)
+        fut = self._pool.submit(self._run, i, d_ptr, stride, n_points, n_frames, prm, host)
         self._busy[i] = fut
         return fut
 

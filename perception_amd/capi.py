@@ -93,7 +93,7 @@ class CdTiming(C.Structure):
         ("icp_kernel_launches", C.c_int32),
         ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32), ("icp_persist_gave_up", C.c_int32),
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
-        ("scan_retries", C.c_int32), ("reserved", C.c_int32),
+        ("scan_retries", C.c_int32), ("icp_regime", C.c_int32),
     ]
 
 
@@ -325,6 +325,13 @@ class Context:
                                                      points_per_frame, n_frames, C.byref(prm),
                                                      C.cast(res, C.c_void_p), _ptr(plane_inliers),
                                                      _ptr(labels)))
+        return res
+
+    def process_batch_host_ptr(self, host_ptr, stride_bytes, points_per_frame, n_frames, prm, results=None):
+        """cd_process_batch on a raw HOST pointer (e.g. a pinned torch tensor's data_ptr()): the upload is part of the call."""
+        res = results if results is not None else (CdFrameResult * n_frames)()
+        self._check(self.lib.cd_process_batch(self.h, C.c_void_p(host_ptr), stride_bytes, points_per_frame, n_frames,
+                                              C.byref(prm), C.cast(res, C.c_void_p), None, None))
         return res
 
     def cluster_results(self, frame, first=0, count=None):

@@ -29,11 +29,10 @@ constexpr int ICP_SUB = 64;                // template run length that carries o
 #ifndef CD_PIPE_SLOTS
 #define CD_PIPE_SLOTS 4                    // most clusters a workgroup of k_icp_pipe / k_icp_pipe_big can keep in flight (IcpParams::pipe_slots)
 #endif
-// template points resident in LDS: 118 runs (118 KiB) with two pipeline slots; slots three to six (312 B each: state + moment
-// sums) fit into ONE run of the image (64 x (16 + 2) B) less.  (Round 4: one run went to the eight 64-bit words per wave of
-// the pair search, k_icp.hip search_pairs - 1 KiB; rounds 2-3 held 7616 / 7552 points.)
+// template points resident in LDS: 119 runs (119 KiB) with two pipeline slots, which leave 288 bytes of the CU's 160 KiB;
+// slots three to six (312 B each: state + moment sums) fit into ONE run of the image (64 x (16 + 2) B) less
 static_assert(CD_PIPE_SLOTS >= 1 && CD_PIPE_SLOTS <= 6, "LDS budget of k_icp_pipe");
-constexpr int ICP_TPL_LDS = CD_PIPE_SLOTS <= 2 ? 7552 : 7488;
+constexpr int ICP_TPL_LDS = CD_PIPE_SLOTS <= 2 ? 7616 : 7552;
 constexpr int ICP_MAX_CELLS = 12288;       // cells of the template's uniform grid (uint16 start table, 24 KiB of LDS)
 constexpr int ICP_CELL_STRIDE = ICP_MAX_CELLS + 8;   // table entries reserved per template slot
 constexpr int ICP_MAX_CHUNKS = 12;         // k-d subtree chunks of a template that does not fit LDS
@@ -230,17 +229,20 @@ __device__ __forceinline__ float dist2(float ax, float ay, float az, float bx, f
     const float dx = ax - bx, dy = ay - by, dz = az - bz;
     return __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
 }
-// A workgroup's place in a grid from an atomic TICKET instead of blockIdx (round 4).  The chained scans below wait for tiles
-// with smaller ids; a workgroup that holds ticket t exists only after tickets 0..t-1 were drawn, by workgroups that are
-// running or done - so every wait ends, whatever order the hardware starts a grid's workgroups in and whoever else shares
-// the GPU (several contexts in flight: until round 3 the ids came from blockIdx and the argument rested on the dispatch
-// order).  The workgroup that draws the grid's last ticket puts the counter back to zero for the next launch (the launches
-// that share a counter are ordered on one stream).  One device-scope atomic round trip before the first load; ends with a
-// workgroup barrier.  `s_ticket`: one int of LDS.
-__device__ __forceinline__ int take_ticket(int* counter, int* s_ticket) {
+// A workgroup's TILE from an atomic ticket instead of blockIdx (round 4).  The chained scans below wait for tiles of the same
+// frame with smaller ids; a workgroup that holds ticket t of a frame exists only after tickets 0..t-1 of that frame were
+// drawn, by workgroups that are running or done - so every wait ends, whatever order the hardware starts a grid's
+// workgroups in and whoever else shares the GPU (several contexts in flight: until round 3 the ids came from blockIdx and
+// the argument rested on the dispatch order).  One counter PER FRAME, TICKET_PITCH ints apart: a single counter for the
+// whole grid serialises 38 400 same-address atomics per launch (measured: crop + voxel 0.98 -> 1.37 ms); per frame it is
+// ~150.  The workgroup that draws a frame's last ticket puts its counter back to zero for the next launch (the launches
+// that share the counters are ordered on one stream).  One device-scope atomic round trip before the first load; ends
+// with a workgroup barrier.  `s_ticket`: one int of LDS.
+constexpr int TICKET_PITCH = 32;   // ints between the counters of two frames (128 bytes: one L2 line each)
+__device__ __forceinline__ int take_ticket(int* counter, int tickets, int* s_ticket) {
     if (threadIdx.x == 0) {
         const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == (int)(gridDim.x * gridDim.y * gridDim.z) - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == tickets - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *s_ticket = t;
     }
     __syncthreads();

@@ -41,7 +41,7 @@ struct cd_context {
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_ghist = nullptr;
     int* d_sstate = nullptr;   // chained-scan state of the radix passes, [pass][F][tiles][256]
-    int* d_ticket = nullptr;   // ticket counter of the kernels that scan over tiles (take_ticket, common.hpp): zero between launches
+    int* d_ticket = nullptr;   // ticket counters, one per frame (TICKET_PITCH ints apart), of the kernels that scan over tiles (take_ticket, common.hpp): zero between launches
     // RANSAC
     int* d_rnd = nullptr;
     float4* d_models = nullptr;
@@ -149,19 +149,29 @@ int fail(cd_context* c, int code, const char* msg) {
 }
 
 // ---- chained scans and several contexts on one GPU ---------------------------------------------------------------------------
-// A chained scan (crop, radix scatters, voxel heads, cd_extract) waits for tiles with smaller ids.  Within ONE grid that is
-// safe: every XCD starts its share of the workgroups in id order, so the unfinished tile with the smallest id is always
-// running or next in line on an XCD that holds nothing but finished-or-running tiles of the same grid.  With several
-// contexts in flight (BatchPipeline) the argument has a hole: grid A's waiting workgroups can fill the XCD that grid B's
-// next tile needs while B's fill the one A needs.  The waits are bounded (common.hpp), the kernel then reports
-// scan_stalled, and the call is REDONE ALONE: every compute call holds this per-device lock shared, the retry exclusively,
-// so no other context of the process has a kernel in flight while it runs.  (Never seen on hardware; CUBOID_FORCE_SCAN_STALL
-// exercises the path.)
+// A chained scan (crop, radix scatters, voxel heads, cd_extract) waits for tiles with smaller ids.  Since round 4 the ids are
+// atomic tickets (take_ticket, common.hpp): the holder of a ticket has started, so a wait can only be for a workgroup that is
+// running or done - finite by construction, whatever else shares the GPU.  (Rounds 1-3 took the ids from blockIdx and relied
+// on the order in which an XCD starts a grid's workgroups; with several contexts in flight that argument had a hole.)  What is
+// left of the old answer to that hole is a safety net that cannot trigger on its own: the waits are still bounded
+// (common.hpp), a kernel that gives up reports scan_stalled, and the call is REDONE ALONE - every compute call holds this
+// per-device lock shared, the redo exclusively.  CUBOID_FORCE_SCAN_STALL exercises the path.
+// The redo must not starve: libstdc++'s shared_mutex is a reader-preferring pthread_rwlock, and with five contexts calling
+// back to back some reader nearly always holds it.  So every call first passes a turnstile (a plain mutex, taken and
+// released at once); a redo holds the turnstile while it waits for the exclusive lock - new calls queue behind it, the
+// calls in flight drain, the redo runs, the queue moves on (tests/test_gpu_readback_guess.py, saturated pipeline).
 constexpr int CD_INTERNAL_STALL = -100;   // never leaves the library
 constexpr int MAX_DEVICES = 16;
 std::shared_mutex g_scan_mu[MAX_DEVICES];
+std::mutex g_turnstile[MAX_DEVICES];
 std::atomic<int> g_calls_in_flight[MAX_DEVICES];
 
+std::atomic<int> g_batches_in_flight[MAX_DEVICES];   // fused batch calls only: what the launch regime of the whole-cluster ICP kernel looks at
+struct BatchGuard {  // (a cd_bbox_filter or cd_extract beside a batch must not change the shape of its ICP launch)
+    int dev;
+    explicit BatchGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_batches_in_flight[dev].fetch_add(1); }
+    ~BatchGuard() { g_batches_in_flight[dev].fetch_sub(1); }
+};
 struct CallGuard {   // one per compute call: counts the contexts at work on the device (k_icp_persist wants the chip to itself)
     int dev;
     explicit CallGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_calls_in_flight[dev].fetch_add(1); }
@@ -173,6 +183,7 @@ int with_scan_retry(cd_context* c, Fn&& fn) {
     const int dev = c->device & (MAX_DEVICES - 1);
     int st;
     {
+        { std::lock_guard<std::mutex> pass(g_turnstile[dev]); }   // held by a pending redo: wait behind it
         std::shared_lock<std::shared_mutex> lk(g_scan_mu[dev]);
         CallGuard g(dev);
         st = fn();
@@ -182,7 +193,8 @@ int with_scan_retry(cd_context* c, Fn&& fn) {
     c->scan_retries += 1;
     hipStreamSynchronize(c->stream);
     {
-        std::unique_lock<std::shared_mutex> lk(g_scan_mu[dev]);
+        std::lock_guard<std::mutex> hold(g_turnstile[dev]);          // no new call starts until this redo is done
+        std::unique_lock<std::shared_mutex> lk(g_scan_mu[dev]);      // ... and the calls in flight have drained
         CallGuard g(dev);
         st = fn();
     }
@@ -291,9 +303,9 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
         }
     }
     int st = CD_OK;
-    // (the ticket counter resets itself at the end of every launch that uses it; zeroed here too so that a call that failed
-    // half way can never leave the next one with a counter that is not zero)
-    HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+    // (the ticket counters reset themselves at the end of every launch that uses them; zeroed here too so that a call that
+    // failed half way can never leave the next one with a counter that is not zero)
+    HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int) * (size_t)F * TICKET_PITCH, c->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
@@ -604,7 +616,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // 4 per XCD and shader engine - lose 2-4 %).
     // (crossover measured on config 3: with two calls in flight the two shapes tie, with three 2 x 256 wins 49.4 : 46.5 k, with
     // four 4 x 128 wins 52.9 : 49.7 k - and the last launches of a burst, which soon have the GPU to themselves, spread out)
-    const bool crowded = g_calls_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 4;
+    const bool crowded = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 4;
     ip.pipe_slots = c->icp_slots > 0 ? std::min(c->icp_slots, CD_PIPE_SLOTS) : (crowded ? CD_PIPE_SLOTS : std::min(2, CD_PIPE_SLOTS));
     ip.pad_ = 0;
     auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
@@ -691,6 +703,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             HIPCHK(c, hipStreamWaitEvent(c->stream, c->ev2[1], 0));
         }
         c->timing.icp_kernel_launches = 1;
+        c->timing.icp_regime = (ipg.pipe_slots << 16) | n_wg;
         if (nwork == 0) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
             HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
@@ -720,6 +733,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
             HIPCHK(c, hipStreamWaitEvent(si, c->ev2[0], 0));
         }
+        if (pipe_ok || big_ok) c->timing.icp_regime = (ip.pipe_slots << 16) | pipe_grid(ncl, wg_cap);
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                             c->d_queue, pipe_grid(ncl, wg_cap), nullptr, ip));
@@ -906,6 +920,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     if (N > c->N || F > c->F) return fail(c, CD_ERR_CAPACITY, "batch larger than the context capacity");
     invalidate_last(c);
     std::memset(&c->timing, 0, sizeof(c->timing));
+    BatchGuard in_flight(c->device);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int rounds = 0;
     st = stage_crop_voxel(c, d_frames, stride, N, F, p, nullptr);
@@ -1250,7 +1265,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
     ok = ok && dalloc(&c->d_ghist, F * SORT_MAX_PASSES_HOST * RADIX) == hipSuccess;
     ok = ok && dalloc(&c->d_sstate, (size_t)SORT_MAX_PASSES_HOST * F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
-    ok = ok && dalloc(&c->d_ticket, 4) == hipSuccess && hipMemset(c->d_ticket, 0, sizeof(int) * 4) == hipSuccess;
+    ok = ok && dalloc(&c->d_ticket, (size_t)F * TICKET_PITCH) == hipSuccess && hipMemset(c->d_ticket, 0, sizeof(int) * (size_t)F * TICKET_PITCH) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
     ok = ok && halloc(&c->h_valid, F * MAX_HYP) == hipSuccess && halloc(&c->h_counts, F * MAX_HYP) == hipSuccess && halloc(&c->h_models, F * MAX_HYP) == hipSuccess;

@@ -388,8 +388,12 @@ template <int SH = 13, bool PK = false>
 __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
                                             QueryRegs& q, int pad) {
     // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
-    // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it)
-    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)KeyFmt<SH>::NONE;
+    // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it).
+    // PK (k_icp_pipe since round 4): the caller hands over the SEED'S OWN KEY - q.pbest = d2(q, seed) exactly, q.poi = the
+    // seed's key word ("no index" when there is no seed) - so the minimum starts at the seed and only a strictly better
+    // candidate (closer, or as close with a lower original index) moves it: same result, and a query whose neighbour did not
+    // change needs no write-back
+    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)(PK ? (unsigned)q.poi : KeyFmt<SH>::NONE);
     const float slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
     const float sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
     const float slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
@@ -486,7 +490,7 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
         }
     }
     const unsigned lo = (unsigned)(lkey & 0xffffffffull);
-    if (act && lo != KeyFmt<SH>::NONE) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & KeyFmt<SH>::POS_MASK); q.poi = (int)(lo >> SH); }
+    if (act && lo != KeyFmt<SH>::NONE) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & KeyFmt<SH>::POS_MASK); q.poi = PK ? (int)lo : (int)(lo >> SH); }
 }
 
 // Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
@@ -574,19 +578,37 @@ __device__ __forceinline__ void search_chunk(const float4* s_tpl, const RunBoxes
 // paid: the lexicographic update as ONE 64-bit unsigned compare (the compiler turned "d < best || (d == best && oi < boi)"
 // into two nested exec-mask regions with branches per patch), 6.4 -> 6.0 ms.  What did not: two queries interleaved per trip
 // (same time: the SGPR pressure of two mask/coordinate sets spills to VGPR lanes).
-struct FarQ { float x, y, z, best; unsigned long long m0, m1; unsigned long long lkey; };   // lkey = d2 bits : (original index << 13 | stored position)
+struct FarQ { float x, y, z, best; unsigned long long m0, m1; unsigned long long lkey, seed; };   // lkey = d2 bits : (original index << 13 | stored position); seed: the query's seed key (wave-uniform)
 
-__device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const QueryRegs& q, int need, int k) {
+// m with bit k cleared, in ONE scalar instruction (the compiler's m & (m - 1) is s_add_u32 + s_addc_u32 + s_and_b64).  The
+// scalar unit is shared by the sixteen waves of the workgroup, and the far search issues 0.8 scalar instructions per vector
+// instruction - three quarters of the kernel's scalar instructions (profiles/r04_valu_calibration.txt):
+// every scalar instruction taken out of these loops is worth more than a vector one.
+__device__ __forceinline__ unsigned long long clear_bit64(unsigned long long m, int k) {
+#ifndef CD_NO_SALU_DIET
+    asm("s_bitset0_b64 %0, %1" : "+s"(m) : "s"(k));
+    return m;
+#else
+    return m & (m - 1ull);   // (callers pass the lowest set bit)
+#endif
+}
+
+// The query enters with ITS SEED'S KEY (round 4): q.pbest = d2(q, seed) exactly, q.poi = the seed's key word.  The box
+// test `lb <= d2(q, seed)` keeps every patch that can hold a point as close as the seed (closer, or equally close with a lower
+// original index); the lanes' running minima start at the seed key, so "some lane's key is below the seed key" says exactly
+// "the neighbour changes" - and when it does not (the usual case once ICP has settled) the query is done after the visits:
+// no reduction, no write-back.  Both halves' boxes are always tested: the per-query flag that skipped an unreachable half cost
+// a readlane, two scalar bit tests and two branches to save eleven vector instructions - on a scalar unit that sixteen waves share.
+__device__ __forceinline__ void far_begin(FarQ& f, const RunBoxes& bx, const QueryRegs& q, int k) {
     f.x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
     f.y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
     f.z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
     f.best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-    const int nd = __builtin_amdgcn_readlane(need, k);
-    f.m0 = 0ull; f.m1 = 0ull;
-    if (nd & 1) f.m0 = ballot64(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
-    if (nd & 2) f.m1 = ballot64(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
-    // lanes start from (bound, no index): a lane can only be selected if it beat the bound, and the seed point itself does
-    f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
+    const unsigned kw = (unsigned)__builtin_amdgcn_readlane(q.poi, k);
+    f.m0 = ballot64(box_lb(bx.L0, bx.H0, f.x, f.y, f.z) <= f.best);
+    f.m1 = ballot64(box_lb(bx.L1, bx.H1, f.x, f.y, f.z) <= f.best);
+    f.lkey = ((unsigned long long)__float_as_uint(f.best) << 32) | (unsigned long long)kw;
+    f.seed = f.lkey;
 }
 __device__ __forceinline__ int far_next_patch(FarQ& f, int psplit) {   // wave-uniform; f.m0 | f.m1 != 0
     int r;
@@ -612,14 +634,18 @@ __device__ __forceinline__ void far_take(FarQ& f, const float4& t, int pos) {
 // which cost more than the box tests (probe: the tail run twice = +1.05 ms of 5.9).
 __device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsigned long long* slot) {
     const int lane = threadIdx.x & 63;
-    const unsigned long long bound = ((unsigned long long)__float_as_uint(f.best) << 32) | 0x7fffffffull;
-    // lanes whose key beats the bound.  None: the query keeps its seed.  Exactly one (the usual case once the seeds are
-    // tight: the seed point itself, in the one patch that holds it): that key IS the minimum, fetched with two readlanes.
-    // Several: LDS 64-bit min over them.
+    const unsigned long long bound = f.seed;
+    // lanes whose key beats the seed's.  None (the usual case once ICP has settled: the neighbour is still the seed): the
+    // query keeps it, nothing to do.  Exactly one: that key IS the minimum, fetched with two readlanes.  Several: LDS 64-bit
+    // min over them.
     const unsigned long long imp = ballot64(f.lkey < bound);
     if (imp == 0ull) return;
     unsigned long long res;
+#ifndef CD_NO_SALU_DIET
+    if (__popcll(imp) == 1) {
+#else
     if ((imp & (imp - 1ull)) == 0ull) {
+#endif
         const int src = __ffsll((long long)imp) - 1;
         const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(f.lkey >> 32), src);
         const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)f.lkey, src);
@@ -633,276 +659,49 @@ __device__ __forceinline__ void far_end(const FarQ& f, QueryRegs& q, int k, unsi
     const unsigned lo = (unsigned)res;
     q.pbest = mine ? __uint_as_float((unsigned)(res >> 32)) : q.pbest;
     q.pbi = mine ? (int)(lo & 0x1fffu) : q.pbi;
-    q.poi = mine ? (int)(lo >> 13) : q.poi;
+    q.poi = mine ? (int)lo : q.poi;
 }
 template <bool PK = false>
 __device__ __forceinline__ void search_patches(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, int cn, QueryRegs& q,
-                                               unsigned long long todo, int psplit, int need, unsigned long long* slot, int* stat_acc = nullptr) {
+                                               unsigned long long todo, int psplit, unsigned long long* slot, int* stat_acc = nullptr) {
     const int lane = threadIdx.x & 63;
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
+        todo = clear_bit64(todo, k);
         FarQ A;
-        far_begin(A, bx, q, need, k);
+        far_begin(A, bx, q, k);
 #ifdef CD_STATS
         if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)(__popcll(A.m0) + __popcll(A.m1))); atomicAdd(&g_icp_stats[2], 1ull); }
 #endif
 #ifdef CD_ITSTATS
         if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += __popcll(A.m0) + __popcll(A.m1); }
 #endif
+#ifndef CD_NO_SALU_DIET
+        // the two halves' masks one after the other: no per-patch choice between them (three scalar instructions and a branch)
+        while (A.m0) {
+            const int r = __ffsll((long long)A.m0) - 1;
+            A.m0 = clear_bit64(A.m0, r);
+            const int pos = s_kd[r * ICP_SUB + lane];
+            far_take<PK>(A, s_tpl[pos], pos);
+        }
+        const unsigned short* s_kd1 = s_kd + psplit * ICP_SUB;   // (the right half's table: no per-patch scalar add)
+        while (A.m1) {
+            const int r = __ffsll((long long)A.m1) - 1;
+            A.m1 = clear_bit64(A.m1, r);
+            const int pos = s_kd1[r * ICP_SUB + lane];
+            far_take<PK>(A, s_tpl[pos], pos);
+        }
+#else
         while (A.m0 | A.m1) {
             const int r = far_next_patch(A, psplit);
             const int pos = s_kd[r * ICP_SUB + lane];
             far_take<PK>(A, s_tpl[pos], pos);
         }
+#endif
         far_end(A, q, k, slot);
     }
 }
 
-
-// ---------------------------------------------------------------------------------------
-// The same search as a list of (query, patch) PAIRS (round 4).  search_patches handles one far query at a time, and everything
-// a query needs is one dependent chain: five readlanes -> box tests -> ballot -> per patch (position read -> LDS round trip ->
-// point read -> LDS round trip -> distance -> minimum) -> ballot -> readlanes or three more LDS operations.  The counters say
-// what that costs (profiles/r04_valu_calibration.txt, r04_pmc_wait.txt): a wave of k_icp_pipe sits at an s_waitcnt for half of
-// its life and the vector pipe is a third used - the kernel is bound by those chains, not by issue slots.  Here the far queries
-// of a pass are taken FAR_CHUNK at a time and the phases are separated, so that independent work is in flight together:
-//   P1  per query of the chunk: readlanes, box tests, ballots - and every surviving patch is filed as a pair
-//       (slot j, query lane k, patch r) in lane `np++` of ONE vector register (v_writelane): no LDS operation at all;
-//   P2  the pairs are drained two at a time: both pairs' position reads go out together, then both point reads, then both
-//       distances; a lane whose candidate beats its query's bound lowers the query's LDS word (ds_min_u64 on slot j - the
-//       lexicographic (d2, original index) minimum of rule C5 is an unsigned 64-bit minimum of the keys, hence order-free);
-//   P3  lane-parallel: every query lane of the chunk reads its word back.
-// Same candidates, same keys, same minimum: bit-identical results.  A query that more than FAR_PAIRS patches survive (a loose
-// bound in the first iterations) is searched by search_patches' loop on its own.
-// ---------------------------------------------------------------------------------------
-constexpr int FAR_CHUNK = 8;    // far queries per chunk = 64-bit LDS words per wave
-constexpr int FAR_PAIRS = 64;   // pairs per chunk = lanes of the pair register
-
-// v[lane] = val (both wave-uniform).  (This compiler has no __builtin_amdgcn_writelane; two scalar registers in one VOP3
-// violate gfx9's constant-bus limit, so the lane select goes through M0.)
-__device__ __forceinline__ int writelane_i32(int v, int val, int lane) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(v) : "s"(val), "s"(lane) : "m0");
-    return v;
-}
-
-template <bool PK>
-__device__ __forceinline__ void far_one_query(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q, int k,
-                                              int psplit, int need, unsigned long long* slot) {
-    const int lane = threadIdx.x & 63;
-    FarQ A;
-    far_begin(A, bx, q, need, k);
-    while (A.m0 | A.m1) {
-        const int r = far_next_patch(A, psplit);
-        const int pos = s_kd[r * ICP_SUB + lane];
-        far_take<PK>(A, s_tpl[pos], pos);
-    }
-    far_end(A, q, k, slot);
-}
-
-template <bool PK>
-__device__ __forceinline__ void search_pairs(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q,
-                                             unsigned long long todo, int psplit, int need, unsigned long long* slots, int* stat_acc = nullptr) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = lanemask_lt();
-#ifdef CD_TIMERS
-    long long tf_[3] = {0, 0, 0}, tfl_ = clock64();
-    unsigned nfq_ = 0, nfp_ = 0;
-#define CD_FARPH(n) { const long long t_ = clock64(); tf_[n] += t_ - tfl_; tfl_ = t_; }
-#else
-#define CD_FARPH(n)
-#endif
-    while (todo) {
-        // ---- P1: box tests of up to FAR_CHUNK queries; their surviving patches become pairs in the lanes of vpair
-        unsigned long long chunk = 0ull;
-        int vpair = 0, np = 0, nq = 0;
-        while (todo && nq < FAR_CHUNK) {
-            const int k = __ffsll((long long)todo) - 1;
-            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
-            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
-            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
-            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-            const int nd = __builtin_amdgcn_readlane(need, k);
-            unsigned long long m0 = 0ull, m1 = 0ull;
-            if (nd & 1) m0 = ballot64(box_lb(bx.L0, bx.H0, x, y, z) <= best);
-            if (nd & 2) m1 = ballot64(box_lb(bx.L1, bx.H1, x, y, z) <= best);
-            const int cnt = __popcll(m0) + __popcll(m1);
-            if (np + cnt > FAR_PAIRS) {
-                if (nq > 0) break;                  // the chunk is full: this query opens the next one
-                todo &= todo - 1;                   // more patches than a chunk holds: the one-query loop
-                far_one_query<PK>(s_tpl, s_kd, bx, q, k, psplit, need, slots);
-#ifdef CD_STATS
-                if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
-#endif
-                continue;
-            }
-            todo &= todo - 1;
-            chunk |= 1ull << k;
-#ifdef CD_STATS
-            if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
-#endif
-#ifdef CD_ITSTATS
-            if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += cnt; }
-#endif
-            const int tag = (nq << 13) | (k << 7);
-            while (m0) {
-                const int r = __ffsll((long long)m0) - 1;
-                m0 &= m0 - 1;
-                vpair = writelane_i32(vpair, tag | r, np);
-                ++np;
-            }
-            while (m1) {
-                const int r = psplit + __ffsll((long long)m1) - 1;
-                m1 &= m1 - 1;
-                vpair = writelane_i32(vpair, tag | r, np);
-                ++np;
-            }
-            ++nq;
-        }
-        if (nq == 0) continue;
-        // every query lane of the chunk puts its bound (d2 bound : no index) into its word; LDS operations of one wave execute
-        // in program order, so the minima below see it
-        const bool mine = (chunk >> lane) & 1ull;
-        const int rank = __popcll(chunk & lt);
-        const unsigned long long bound = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
-        if (mine) __hip_atomic_store(&slots[rank], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        CD_FARPH(0)
-#ifdef CD_TIMERS
-        nfq_ += (unsigned)nq; nfp_ += (unsigned)np;
-#endif
-        // ---- P2: two pairs per trip (an odd one out is done twice: the minimum does not mind)
-        for (int p = 0; p < np; p += 2) {
-            const int e0 = __builtin_amdgcn_readlane(vpair, p);
-            const int e1 = __builtin_amdgcn_readlane(vpair, p + 1 < np ? p + 1 : p);
-            const int k0 = (e0 >> 7) & 63, k1 = (e1 >> 7) & 63;
-            const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k0));
-            const float y0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k0));
-            const float z0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k0));
-            const unsigned b0 = (unsigned)__builtin_amdgcn_readlane(__float_as_int(q.pbest), k0);
-            const float x1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k1));
-            const float y1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k1));
-            const float z1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k1));
-            const unsigned b1 = (unsigned)__builtin_amdgcn_readlane(__float_as_int(q.pbest), k1);
-            const int pos0 = s_kd[(e0 & 127) * ICP_SUB + lane];
-            const int pos1 = s_kd[(e1 & 127) * ICP_SUB + lane];
-            const float4 t0 = s_tpl[pos0];
-            const float4 t1 = s_tpl[pos1];
-            const float d0 = dist2(x0, y0, z0, t0.x, t0.y, PK ? t0.w : t0.z);   // (PK images are stored (x, y, key word, z))
-            const float d1 = dist2(x1, y1, z1, t1.x, t1.y, PK ? t1.w : t1.z);
-            const unsigned long long key0 = ((unsigned long long)__float_as_uint(d0) << 32) | (PK ? (unsigned)__float_as_int(t0.z) : (((unsigned)__float_as_int(t0.w) << 13) | (unsigned)pos0));
-            const unsigned long long key1 = ((unsigned long long)__float_as_uint(d1) << 32) | (PK ? (unsigned)__float_as_int(t1.z) : (((unsigned)__float_as_int(t1.w) << 13) | (unsigned)pos1));
-            if (key0 < (((unsigned long long)b0 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e0 >> 13], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (key1 < (((unsigned long long)b1 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e1 >> 13], key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        CD_FARPH(1)
-        // ---- P3: the query lanes read their words back
-        if (mine) {
-            const unsigned long long res = __hip_atomic_load(&slots[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const unsigned lo = (unsigned)res;
-            if (lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(res >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
-        }
-        CD_FARPH(2)
-    }
-#ifdef CD_TIMERS
-    if (lane == 0 && (nfq_ | nfp_)) {   // cycles in P1 / P2 / P3, far queries, pairs (slots 0..4 are free in a CD_TIMERS build)
-        atomicAdd(&g_icp_stats[0], (unsigned long long)tf_[0]); atomicAdd(&g_icp_stats[1], (unsigned long long)tf_[1]);
-        atomicAdd(&g_icp_stats[2], (unsigned long long)tf_[2]); atomicAdd(&g_icp_stats[3], (unsigned long long)nfq_);
-        atomicAdd(&g_icp_stats[4], (unsigned long long)nfp_);
-    }
-#endif
-#undef CD_FARPH
-}
-
-// The pair search with NO scalar round trips in its inner loops (round 4, second form).  The first form above keeps the pair
-// list in a vector register and reads it, and the queries' coordinates, back with v_readlane: every pair then starts with a
-// chain VALU -> SGPR -> SALU -> VALU -> LDS, and the timers showed ~360 cycles per pair and ~780 per query in P1 for ~55
-// instructions: it is those hops between the vector and the scalar side, not the LDS round trips alone, that a far query's
-// time consists of.  Here
-//   P1  files the pairs lane-parallel: the lanes whose patch box passed write (slot, query lane, patch) as 16-bit entries at
-//       list[np + mbcnt(mask)] - one ds_write_b16 under the ballot's own mask, no scalar loop over the set bits;
-//   P2  is vector-only: the entry is a broadcast LDS read, the query's coordinates come through ds_bpermute (the LDS crossbar,
-//       no memory), addresses are vector arithmetic; two pairs per trip, all loads of both in flight together;
-//   P3  as before.
-// LDS per wave: FAR_CHUNK 64-bit words + FAR_LIST 16-bit entries (192 bytes).
-constexpr int FAR_LIST = 32;    // pairs per chunk (second form)
-template <bool PK>
-__device__ __forceinline__ void search_pairs_v(const float4* s_tpl, const unsigned short* s_kd, const RunBoxes& bx, QueryRegs& q,
-                                               unsigned long long todo, int psplit, int need, unsigned long long* slots,
-                                               unsigned short* list, int* stat_acc = nullptr) {
-    const int lane = threadIdx.x & 63;
-    const unsigned long long lt = lanemask_lt();
-    while (todo) {
-        unsigned long long chunk = 0ull;
-        int np = 0, nq = 0;
-        while (todo && nq < FAR_CHUNK) {
-            const int k = __ffsll((long long)todo) - 1;
-            const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
-            const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
-            const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
-            const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-            const int nd = __builtin_amdgcn_readlane(need, k);
-            unsigned long long m0 = 0ull, m1 = 0ull;
-            if (nd & 1) m0 = ballot64(box_lb(bx.L0, bx.H0, x, y, z) <= best);
-            if (nd & 2) m1 = ballot64(box_lb(bx.L1, bx.H1, x, y, z) <= best);
-            const int c0 = __popcll(m0), cnt = c0 + __popcll(m1);
-            if (np + cnt > FAR_LIST) {
-                if (nq > 0) break;
-                todo &= todo - 1;
-                far_one_query<PK>(s_tpl, s_kd, bx, q, k, psplit, need, slots);
-#ifdef CD_STATS
-                if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
-#endif
-                continue;
-            }
-            todo &= todo - 1;
-            chunk |= 1ull << k;
-#ifdef CD_STATS
-            if (lane == 0) { atomicAdd(&g_icp_stats[1], (unsigned long long)cnt); atomicAdd(&g_icp_stats[2], 1ull); }
-#endif
-#ifdef CD_ITSTATS
-            if (stat_acc) { stat_acc[0] += 1; stat_acc[1] += cnt; }
-#endif
-            const int tag = (nq << 13) | (k << 7);
-            if ((m0 >> lane) & 1ull) list[np + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m0 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m0, 0u))] = (unsigned short)(tag | lane);
-            if ((m1 >> lane) & 1ull) list[np + c0 + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u))] = (unsigned short)(tag | (psplit + lane));
-            np += cnt;
-            ++nq;
-        }
-        if (nq == 0) continue;
-        const bool mine = (chunk >> lane) & 1ull;
-        const int rank = __popcll(chunk & lt);
-        const unsigned long long bound = ((unsigned long long)__float_as_uint(q.pbest) << 32) | 0x7fffffffull;
-        if (mine) __hip_atomic_store(&slots[rank], bound, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        for (int p = 0; p < np; p += 2) {
-            const int e0 = list[p];
-            const int e1 = list[p + 1 < np ? p + 1 : p];
-            const int a0 = (e0 >> 5) & 0xfc, a1 = (e1 >> 5) & 0xfc;   // byte address of the query lane's dword for ds_bpermute
-            const int pos0 = s_kd[(e0 & 127) * ICP_SUB + lane];
-            const int pos1 = s_kd[(e1 & 127) * ICP_SUB + lane];
-            const float x0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.px)));
-            const float y0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.py)));
-            const float z0 = __int_as_float(__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.pz)));
-            const unsigned b0 = (unsigned)__builtin_amdgcn_ds_bpermute(a0, __float_as_int(q.pbest));
-            const float x1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.px)));
-            const float y1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.py)));
-            const float z1 = __int_as_float(__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.pz)));
-            const unsigned b1 = (unsigned)__builtin_amdgcn_ds_bpermute(a1, __float_as_int(q.pbest));
-            const float4 t0 = s_tpl[pos0];
-            const float4 t1 = s_tpl[pos1];
-            const float d0 = dist2(x0, y0, z0, t0.x, t0.y, PK ? t0.w : t0.z);   // (PK images are stored (x, y, key word, z))
-            const float d1 = dist2(x1, y1, z1, t1.x, t1.y, PK ? t1.w : t1.z);
-            const unsigned long long key0 = ((unsigned long long)__float_as_uint(d0) << 32) | (PK ? (unsigned)__float_as_int(t0.z) : (((unsigned)__float_as_int(t0.w) << 13) | (unsigned)pos0));
-            const unsigned long long key1 = ((unsigned long long)__float_as_uint(d1) << 32) | (PK ? (unsigned)__float_as_int(t1.z) : (((unsigned)__float_as_int(t1.w) << 13) | (unsigned)pos1));
-            if (key0 < (((unsigned long long)b0 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e0 >> 13], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (key1 < (((unsigned long long)b1 << 32) | 0x7fffffffull)) __hip_atomic_fetch_min(&slots[e1 >> 13], key1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        if (mine) {
-            const unsigned long long res = __hip_atomic_load(&slots[rank], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-            const unsigned lo = (unsigned)res;
-            if (lo != 0x7fffffffu) { q.pbest = __uint_as_float((unsigned)(res >> 32)); q.pbi = (int)(lo & 0x1fffu); q.poi = (int)(lo >> 13); }
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------
 // Wave-per-query search over a template that does NOT fit LDS (more than ICP_TPL_LDS points; up to 65535): the points stay in
@@ -1787,10 +1586,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     __shared__ unsigned short s_cs[ICP_MAX_CELLS + 8];
     __shared__ PipeSlot s_slot[PIPE_SLOTS];
     __shared__ unsigned short s_kd[BIG ? 1 : ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
-    __shared__ unsigned long long s_far[ICPT_WAVES * FAR_CHUNK];   // FAR_CHUNK words per wave: the running minima of the far queries it is on
-#if defined(CD_FAR_PAIRS) && CD_FAR_PAIRS == 2
-    __shared__ unsigned short s_flist[BIG ? 1 : ICPT_WAVES * FAR_LIST];   // the wave's (slot, query, patch) pairs
-#endif
+    __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
     __shared__ float4 s_plo[BIG ? ICP_BIG_PATCHES : 1], s_phi[BIG ? ICP_BIG_PATCHES : 1];   // BIG: boxes of all k-d patches
     constexpr int KSH = BIG ? 16 : 13;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1927,7 +1723,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                                 }
                             }
                             q.pbest = seed_bound(q.pbest);
-                            q.poi = 0;   // (only the chunked searches of the other kernels carry the seed's original index)
+                            q.poi = 0;   // (BIG: only the chunked searches of the other kernels carry the seed's original index; LDS image: set below)
 #ifdef CD_STATS
                             if (lane == 0) atomicAdd(&g_icp_stats[8], (unsigned long long)nk * (unsigned long long)((it > 0 ? 1 : 0) + (it < 3 ? (tpl_m + ICP_SUB - 1) / ICP_SUB : 0)));   // seed tests
 #endif
@@ -1947,6 +1743,16 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
+                    if constexpr (!BIG) {
+                        // from the seed BOUND (next float above d2(q, seed): what the radius of the walk is derived from) to the
+                        // seed's own KEY for both searches: d2 exactly (the bound's bit pattern minus one) and the key word of the
+                        // seed point; a query without a finite seed distance keeps (+inf, no index)
+                        const unsigned bb = __float_as_uint(q.pbest);
+                        const bool fin = bb < 0x7f800000u && lane < nk;
+                        const unsigned kw = fin ? (unsigned)__float_as_int(s_tpl[q.pbi].z) : 0x7fffffffu;
+                        q.pbest = __uint_as_float(fin ? bb - 1u : bb);
+                        q.poi = (int)kw;
+                    }
                     if (ballot64(near)) grid_search<KSH, !BIG>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
@@ -1955,27 +1761,17 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #endif
                     CD_PHASE(2)
                     if constexpr (BIG) {
-                        search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave * FAR_CHUNK]);
+                        search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave]);
                     } else {
-                    // which halves of the template can hold a point within this lane's bound (all lanes at once)
-                    const float4 hl0 = make_float4(g.half_lo[0][0], g.half_lo[0][1], g.half_lo[0][2], 0.f), hh0 = make_float4(g.half_hi[0][0], g.half_hi[0][1], g.half_hi[0][2], 0.f);
-                    const float4 hl1 = make_float4(g.half_lo[1][0], g.half_lo[1][1], g.half_lo[1][2], 0.f), hh1 = make_float4(g.half_hi[1][0], g.half_hi[1][1], g.half_hi[1][2], 0.f);
-                    const int need = (box_lb(hl0, hh0, q.px, q.py, q.pz) <= q.pbest ? 1 : 0) | (box_lb(hl1, hh1, q.px, q.py, q.pz) <= q.pbest ? 2 : 0);
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
-                    search_pairs<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK], stat_acc);
+                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, &s_far[wave], stat_acc);
                     if (lane == 0) {
                         atomicAdd(&g_icp_it[stat_it][0], (unsigned long long)(clock64() - tpass0)); atomicAdd(&g_icp_it[stat_it][1], 1ull);
                         atomicAdd(&g_icp_it[stat_it][2], (unsigned long long)stat_acc[0]); atomicAdd(&g_icp_it[stat_it][3], (unsigned long long)stat_acc[1]);
                     }
 #else
-#ifndef CD_FAR_PAIRS
-                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
-#elif CD_FAR_PAIRS == 2
-                    search_pairs_v<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK], &s_flist[wave * FAR_LIST]);
-#else
-                    search_pairs<true>(s_tpl, s_kd, bx, q, ballot64(lane < nk && !near), psplit, need, &s_far[wave * FAR_CHUNK]);
-#endif
+                    search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, &s_far[wave]);
 #endif
                     }
                     CD_PHASE(4)

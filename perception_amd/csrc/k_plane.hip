@@ -303,7 +303,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict
                                                            FrameState* __restrict__ fs, int* __restrict__ out, int* __restrict__ ticket) {
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_excl, s_ticket;
-    const int tile = take_ticket(ticket, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int tile = take_ticket(ticket, (int)gridDim.x, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;

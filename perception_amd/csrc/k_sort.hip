@@ -105,10 +105,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     __shared__ uint32_t s_bstart[RADIX];                 // where each bin starts inside the tile
     __shared__ uint32_t s_k[SORT_TILE], s_v[SORT_TILE];  // the tile, ordered by bin (64 KiB)
     __shared__ uint32_t s_ws[RADIX / WAVE], s_gs[RADIX / WAVE];
-    // ticket b is tile b / F of frame b % F (see k_crop_fused): a tile's predecessors in the chained scan are long done
+    // workgroup b works on frame b % F and takes its tile by ticket (see k_crop_fused): a tile's predecessors in the chained
+    // scan are long done
     const int F = gridDim.x / Tact, shift = pass * RADIX_BITS;
-    const int b = take_ticket(ticket, &s_ticket);
-    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = use_runs ? fs[f].n_runs : fs[f].n_c;   // (runs: the elements are k_voxel_runs' (voxel index, start | length) pairs)
     if (tile * SORT_TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -257,8 +257,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __res
     __shared__ int s_cnt[SORT_WAVES];
     __shared__ int s_out0, s_ticket;
     const int F = gridDim.x / Tact;
-    const int b = take_ticket(ticket, &s_ticket);
-    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * SORT_TILE >= n) return;
     for (int q = threadIdx.x; q < SORT_MAX_PASSES * RADIX; q += SORT_BLOCK) (&s_h[0][0])[q] = 0;

@@ -207,9 +207,9 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
 
 // ---- single pass: crop + ordered compaction + min/max + absolute voxel coordinates -------
 // One read of the input instead of two.  The exclusive prefix of the tile totals inside a frame comes from chained_scan().
-// The workgroup with ticket b (take_ticket, common.hpp) is tile b / F of frame b % F: the tiles in flight at any time are a
-// few per frame, so a tile's predecessors are usually long done and its look-back ends at the first word; a scan that gives
-// up (it cannot: the guard of chained_scan) sends the batch to the two-pass path.
+// Workgroup b works on frame b % F and takes the frame's next tile by ticket (take_ticket, common.hpp): the tiles in flight
+// at any time are a few per frame, so a tile's predecessors are usually long done and its look-back ends at the first
+// word; a scan that gives up (it cannot: the guard of chained_scan) sends the batch to the two-pass path.
 __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ in, size_t stride, int N, int pitch,
                                                       int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
                                                       FrameState* __restrict__ fs, int* __restrict__ state,
@@ -220,8 +220,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
     __shared__ int s_excl, s_ticket;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int F = gridDim.x / Tin;
-    const int b = take_ticket(ticket, &s_ticket);
-    const int f = b % F, tile = b / F;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tin, &s_ticket);
     const size_t fbase = (size_t)f * N;        // input records
     const size_t obase = (size_t)f * pitch;    // internal arrays
     const int base = tile * TILE + w * WAVE_SPAN;
@@ -329,11 +328,10 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];     // sorted positions of the voxel heads of this tile, in order
     __shared__ int s_out0, s_ticket;
-    // ticket b is tile b / F of frame b % F (see k_crop_fused): the position of a tile's first voxel in the frame's
-    // output comes from a chained scan of the tiles' head counts, so the heads are found once (no count pass + scan)
+    // workgroup b works on frame b % F and takes its tile by ticket (see k_crop_fused): the position of a tile's first voxel in
+    // the frame's output comes from a chained scan of the tiles' head counts, so the heads are found once (no count pass + scan)
     const int F = gridDim.x / Tact;
-    const int b = take_ticket(ticket, &s_ticket);
-    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
     if (tile * TILE >= n) return;
     const size_t fbase = (size_t)f * N;
@@ -418,8 +416,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
     __shared__ int s_head[TILE];
     __shared__ int s_out0, s_ticket;
     const int F = gridDim.x / Tact;
-    const int b = take_ticket(ticket, &s_ticket);
-    const int f = b % F, tile = b / F, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_runs;
     if (tile * TILE >= n) return;
     const size_t fbase = (size_t)f * N;

@@ -1,0 +1,1 @@
+#include <pcl/pcl_stub_core.h>

@@ -273,3 +273,58 @@ def test_stalled_chained_scan_is_redone_alone(O, template, frames4, monkeypatch)
         assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
     finally:
         c.close()
+
+
+def test_stalled_call_is_redone_while_a_pipeline_keeps_the_device_busy(O, template, frames4, monkeypatch):
+    """the redo takes a per-device lock exclusively that every other compute call holds shared, and libstdc++'s
+    shared_mutex prefers readers - with a saturated BatchPipeline (some call always in flight) the redo could wait for
+    ever.  A turnstile in front of the shared lock makes new calls queue behind a pending redo.  Here four contexts run
+    batches back to back from four threads while a fifth context's call reports a (forced) stall: it must come back with
+    the usual results within seconds, and the pipeline's results must not notice."""
+    import threading
+    import time
+    from perception_amd import batch
+    N = synth.WIDTH * synth.HEIGHT
+    fr = np.stack(frames4, 0)
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    import torch
+    d = torch.from_numpy(fr).cuda()
+    torch.cuda.synchronize()
+    pipe = batch.BatchPipeline(N, len(fr), {0: template}, inflight=4)
+    monkeypatch.setenv("CUBOID_FORCE_SCAN_STALL", "1")
+    c = capi.Context(max_points=N, max_frames=2)
+    monkeypatch.delenv("CUBOID_FORCE_SCAN_STALL")
+    stop = threading.Event()
+    recs = []
+
+    def feeder():
+        futs = []
+        while not stop.is_set():
+            futs.append(pipe.submit(d.data_ptr(), 16, N, len(fr), prm))   # blocks while all four contexts are busy: saturated
+            if len(futs) > 8:
+                recs.append(futs.pop(0).result()[0])
+        for f in futs:
+            recs.append(f.result()[0])
+
+    th = threading.Thread(target=feeder)
+    th.start()
+    try:
+        c.set_template(0, template)
+        time.sleep(0.3)                                  # the pipeline is in full swing
+        t0 = time.perf_counter()
+        res, _, _ = c.process_batch(fr[:2], prm)         # stalls (forced), is redone alone
+        dt = time.perf_counter() - t0
+        assert c.timing().scan_retries == 1
+        assert dt < 5.0, "the redo waited %.1f s for the exclusive lock" % dt
+        for f in range(2):
+            o = O.process_frame(frames4[f], prm, template)["result"]
+            assert res[f].n_clusters == o.n_clusters
+            for k in range(o.n_clusters):
+                _same_cluster(res[f].clusters[k], o.clusters[k])
+    finally:
+        stop.set()
+        th.join(120)
+        c.close()
+    assert len(recs) > 8 and all(np.array_equal(r, recs[0]) for r in recs)      # every pipelined batch: the same records
+    pipe.close()

@@ -323,12 +323,11 @@ def test_config5_one_million_points_five_templates(O, mode, monkeypatch):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", ["auto", "pipe"])
-@pytest.mark.parametrize("m", [7424, 7487, 7488, 7489, 7552, 7553, 7616, 7617, 65535, 65536])
+@pytest.mark.parametrize("m", [7488, 7551, 7552, 7553, 7616, 7617, 65535, 65536])
 def test_template_sizes_at_the_kernel_limits(O, m, mode, monkeypatch):
-    """Template sizes either side of the kernels' limits: 7488 points (117 runs) is the last template whose image fits LDS
-    beside four pipeline slots and the pair search's words (k_icp_pipe; 7487 leaves one pad point in its last 64-point run,
-    7424 none), 7489 the first that stays in global memory (k_icp_pipe_big; 7552 / 7553 and 7616 / 7617 were that boundary in
-    round 3, with four and with two slots), 65535 the last a 16-bit
+    """Template sizes either side of the kernels' limits: 7552 points (118 runs) is the last template whose image fits LDS
+    beside four pipeline slots (k_icp_pipe; 7551 leaves one pad point in its last 64-point run, 7488 none), 7553 the first
+    that stays in global memory (k_icp_pipe_big; 7616 / 7617 were that boundary with two slots), 65535 the last a 16-bit
     position can address and 65536 the first that takes the sliced driver.  Random subsets of a denser cuboid template, two
     frames; every size gives the oracle's bits."""
     monkeypatch.setenv("CUBOID_ICP_MODE", mode)

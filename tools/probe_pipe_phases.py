@@ -37,7 +37,5 @@ if hasattr(lib, "cd_debug_icp_stats"):
     tot = max(sum(ph), 1)
     names = ["epoch wait", "fetch+seeds", "grid walk", "solve/hand-over", "far search", "moments+fold"]
     print("CD_TIMERS (3 batches): " + "  ".join("%s %.1f%%" % (n, 100.0 * x / tot) for n, x in zip(names, ph)))
-    if o[3]:   # search_pairs' own timers (round 4): cycles per far query in P1 (box tests), P2 (pairs), P3 (read-back)
-        print("far search by pairs: %d far queries, %.2f pairs each; cycles per query: P1 %.0f  P2 %.0f  P3 %.0f" % (o[3], o[4] / o[3], o[0] / o[3], o[1] / o[3], o[2] / o[3]))
     if o[15]:
         print("workgroup busy time mean %.3f ms, max %.3f ms over %d workgroup launches (balance %.2f)" % (o[14] / max(o[7], 1) / 1e5, o[15] / 1e5, o[7], o[14] / max(o[7], 1) / max(o[15], 1)))
