@@ -61,6 +61,9 @@ struct FrameState {
     int32_t crop_overflow; // single-pass crop: a y cell index did not fit its bit field (the host redoes the batch in two passes)
     int32_t scan_stalled;  // a chained scan gave up waiting for a predecessor tile (reported as CD_ERR_DEVICE)
     int32_t n_runs;        // S1 by runs: runs of equal voxel index among the cropped points (k_voxel_runs; what the sort then moves)
+    int32_t digit_vary;    // k_crop_runs' sort: bit d set when digit d of the packed cell keys takes more than one value in this frame
+                           // (k_voxel_setup reads it off the frame's digit histograms) - the radix passes the sort needs
+    int32_t pad_;
 };
 
 struct CropLimits {        // double limits folded to equivalent float compares (exact)
@@ -274,6 +277,32 @@ __device__ __forceinline__ int chained_scan(int* state, int stride, int tile, in
     }
     __hip_atomic_store(st + (size_t)tile * stride, FLAG_PREFIX | (unsigned)(excl + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return excl;
+}
+// The same for TWO counts at once (k_crop_runs: kept points and runs): a 64-bit word per tile, flag << 62 | second << 31 |
+// first, both counts < 2^31.  Returns the exclusive prefixes through *excl_a / *excl_b.
+__device__ __forceinline__ void chained_scan2(unsigned long long* state, int tile, int tot_a, int tot_b, int* excl_a, int* excl_b,
+                                              int* gave_up) {
+    const unsigned long long FLAG_TOTAL = 1ull << 62, FLAG_PREFIX = 2ull << 62, MASK = (1ull << 31) - 1ull;
+    unsigned long long ea = 0ull, eb = 0ull;
+    if (tile > 0) {
+        __hip_atomic_store(state + tile, FLAG_TOTAL | ((unsigned long long)(unsigned)tot_b << 31) | (unsigned long long)(unsigned)tot_a,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int q = tile - 1; q >= 0; --q) {
+            unsigned long long v;
+            int spins = 0;
+            do {
+                v = __hip_atomic_load(state + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (++spins > (1 << 20)) { *gave_up = 1; v = FLAG_PREFIX; }
+            } while ((v & (FLAG_TOTAL | FLAG_PREFIX)) == 0ull);
+            ea += v & MASK;
+            eb += (v >> 31) & MASK;
+            if (v & FLAG_PREFIX) break;
+        }
+    }
+    __hip_atomic_store(state + tile, FLAG_PREFIX | ((eb + (unsigned long long)(unsigned)tot_b) << 31) | (ea + (unsigned long long)(unsigned)tot_a),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *excl_a = (int)ea;
+    *excl_b = (int)eb;
 }
 // canonical plane distance: |(a*x + b*y) + (c*z + d)|
 __device__ __forceinline__ float plane_dist(float a, float b, float c, float d, float x, float y, float z) {

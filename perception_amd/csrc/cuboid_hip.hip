@@ -41,6 +41,8 @@ struct cd_context {
     float4 *d_cpt = nullptr, *d_vox = nullptr, *d_obj = nullptr, *d_src0 = nullptr, *d_src = nullptr;
     uint32_t *d_key[2] = {nullptr, nullptr}, *d_val[2] = {nullptr, nullptr}, *d_ghist = nullptr;
     int* d_sstate = nullptr;   // chained-scan state of the radix passes, [pass][F][tiles][256]
+    unsigned long long* d_tile64 = nullptr;   // chained-scan state of k_crop_runs: (points, runs) per tile, [F][T]
+    bool crop_runs = true;      // CUBOID_CROP_RUNS=0: the crop writes per-point keys and k_voxel_runs finds the runs (rounds 2-3)
     int* d_ticket = nullptr;   // ticket counters, one per frame (TICKET_PITCH ints apart), of the kernels that scan over tiles (take_ticket, common.hpp): zero between launches
     // RANSAC
     int* d_rnd = nullptr;
@@ -299,9 +301,17 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
                 kp.enabled = 1;
                 kp.bi = bi; kp.bj = 32 - bi - bk;
                 kp.ilo = (int)fl[0]; kp.klo = (int)fl[2]; kp.jlo = -(1 << (kp.bj - 1));
+                // y = 0 sits 256 cells above an aligned block of 512 field values: a frame whose y cells stay within +-256 of the
+                // optical axis (1.28 m at the 5 mm leaf) then has constant y bits above the ninth, and the sort of k_crop_runs,
+                // which runs on these packed keys, skips the digit they fill (3 passes instead of 4 on the bench frames; with y = 0
+                // ON a block boundary every frame straddles it)
+                if (kp.bj >= 11) kp.jlo -= 256;
             }
         }
     }
+    // Round 4: the single-pass crop also writes the RUNS (one record per run of equal cell key inside a row of 64 input points)
+    // and their digit histograms, and the sort runs on the packed cell keys themselves (k_crop_runs, k_voxel.hip)
+    bool crop_runs = kp.enabled && c->crop_runs && c->voxel_runs && c->N <= (1 << 20);
     int st = CD_OK;
     // (the ticket counters reset themselves at the end of every launch that uses them; zeroed here too so that a call that
     // failed half way can never leave the next one with a counter that is not zero)
@@ -309,7 +319,13 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-        if (kp.enabled) {
+        if (kp.enabled && crop_runs) {
+            HIPCHK(c, hipMemsetAsync(c->d_tile64, 0, sizeof(unsigned long long) * (size_t)F * T, c->stream));
+            HIPCHK(c, hipMemsetAsync(c->d_ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX, c->stream));
+            LAUNCH(c, launch_crop_runs(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tile64, c->d_cpt, c->d_key[0], c->d_val[0],
+                             c->d_ghist, c->d_ticket));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, c->d_ghist));
+        } else if (kp.enabled) {
             LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0], c->d_ticket));
             LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
         } else {
@@ -325,11 +341,12 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
         if (!over) break;
         if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: single-pass crop overflowed, redoing the batch in two passes\n");
         kp.enabled = 0;       // rare: redo the crop in two passes (the FrameState init in h_fs was overwritten by the sync)
+        crop_runs = false;
         for (int f = 0; f < F; ++f) {
             FrameState& s = c->h_fs[f];
             std::memset(&s, 0, sizeof(s));
             for (int a = 0; a < 3; ++a) { s.mn[a] = 0xffffffffu; s.mx[a] = 0u; }
-        }
+            }
     }
     int max_nc = 0, max_bits = 0;
     for (int f = 0; f < F; ++f) { max_nc = std::max(max_nc, c->h_fs[f].n_c); max_bits = std::max(max_bits, c->h_fs[f].key_bits); }
@@ -341,7 +358,20 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // order, 2.4 points per run on the bench frames - and the centroid kernel reads the runs' points contiguously; the bound
     // on the tiles is the point count (the run count is only known on the device).  CUBOID_VOXEL_RUNS=0: sort the points.
     const bool by_runs = c->voxel_runs && npass > 0 && c->N <= (1 << 20);   // (a run's start takes 20 bits of its payload)
-    if (by_runs)
+    int Tc_runs = Tc;
+    if (crop_runs) {
+        // the runs and their histograms are there already; which of the packed key's four digits vary in some frame?
+        int vary = 0, max_runs = 0;
+        for (int f = 0; f < F; ++f) {
+            if (c->h_fs[f].n_c > 0) vary |= c->h_fs[f].digit_vary;
+            max_runs = std::max(max_runs, c->h_fs[f].n_runs);
+        }
+        int digits[4], nd = 0;
+        for (int d = 0; d < 4; ++d) if ((vary >> d) & 1) digits[nd++] = d;
+        const int Tsr = std::max(1, (max_runs + SORT_TILE - 1) / SORT_TILE);   // (the run count is known here: tighter than the point count)
+        Tc_runs = std::max(1, (max_runs + TILE - 1) / TILE);
+        LAUNCH(c, cur = launch_radix_scatter_runs(c->stream, c->d_key, c->d_val, c->N, F, Tsr, digits, nd, c->d_fs, c->d_ghist, c->d_sstate, c->d_ticket));
+    } else if (by_runs)
         LAUNCH(c, cur = launch_radix_sort_runs(c->stream, c->d_key, c->d_val, c->N, F, T, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, c->d_tileA, kp, c->d_ticket));
     else
         LAUNCH(c, cur = launch_radix_sort(c->stream, c->d_key, c->d_val, c->N, F, Tsc, npass, c->d_fs, c->d_ghist, c->d_sstate, kp, c->d_ticket));
@@ -350,8 +380,8 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-    if (by_runs)
-        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
+    if (crop_runs || by_runs)
+        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, crop_runs ? Tc_runs : Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
     else
         LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
     if (rounds_out) *rounds_out = 0;
@@ -1222,7 +1252,7 @@ void cd_destroy(cd_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
-                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_ticket, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
+                   c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_ticket, c->d_tile64, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
                    c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
@@ -1265,6 +1295,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
     ok = ok && dalloc(&c->d_ghist, F * SORT_MAX_PASSES_HOST * RADIX) == hipSuccess;
     ok = ok && dalloc(&c->d_sstate, (size_t)SORT_MAX_PASSES_HOST * F * RADIX * ((N + SORT_TILE - 1) / SORT_TILE)) == hipSuccess;
+    ok = ok && dalloc(&c->d_tile64, F * T) == hipSuccess;
     ok = ok && dalloc(&c->d_ticket, (size_t)F * TICKET_PITCH) == hipSuccess && hipMemset(c->d_ticket, 0, sizeof(int) * (size_t)F * TICKET_PITCH) == hipSuccess;
     ok = ok && dalloc(&c->d_rnd, (size_t)RND_TABLE) == hipSuccess;
     ok = ok && dalloc(&c->d_models, F * MAX_HYP) == hipSuccess && dalloc(&c->d_valid, F * MAX_HYP) == hipSuccess && dalloc(&c->d_counts, F * MAX_HYP) == hipSuccess;
@@ -1308,6 +1339,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_FORCE_SCAN_STALL")) c->force_stall = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_CROP_RUNS")) c->crop_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;

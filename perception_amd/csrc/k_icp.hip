@@ -384,16 +384,16 @@ struct KeyFmt {
 };
 // PK: the template image's .w already holds the key's low word (original index << SH | stored position): k_icp_pipe re-labels
 // its LDS image that way once, which takes one vector instruction per tested point out of both searches
-template <int SH = 13, bool PK = false>
+template <int SH = 13, bool PK = false, bool SK = false>
 __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned short* s_cs, const IcpGrid& g, bool act, float rr,
                                             QueryRegs& q, int pad) {
     // running minimum as (d2 bits : original index): the lexicographic update of rule C5 is then ONE unsigned 64-bit compare
     // (no branch, no tie special case; the seed bound enters with "no index" = INT_MAX, so the seed point itself beats it).
-    // PK (k_icp_pipe since round 4): the caller hands over the SEED'S OWN KEY - q.pbest = d2(q, seed) exactly, q.poi = the
-    // seed's key word ("no index" when there is no seed) - so the minimum starts at the seed and only a strictly better
-    // candidate (closer, or as close with a lower original index) moves it: same result, and a query whose neighbour did not
-    // change needs no write-back
-    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)(PK ? (unsigned)q.poi : KeyFmt<SH>::NONE);
+    // SK (k_icp_pipe / k_icp_pipe_big since round 4): the caller hands over the SEED'S OWN KEY - q.pbest = d2(q, seed) exactly,
+    // q.poi = the seed's key word ("no index" when there is no seed) - so the minimum starts at the seed and only a strictly
+    // better candidate (closer, or as close with a lower original index) moves it: same result, and a query whose neighbour
+    // did not change needs no write-back
+    unsigned long long lkey = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)(SK ? (unsigned)q.poi : KeyFmt<SH>::NONE);
     const float slx = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.px), fabsf(g.ox)), __fmul_rn((float)g.nx, g.cell))), 1.0e-7f);
     const float sly = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.py), fabsf(g.oy)), __fmul_rn((float)g.ny, g.cell))), 1.0e-7f);
     const float slz = __fadd_rn(__fmul_rn(4.0e-7f, __fadd_rn(__fadd_rn(fabsf(q.pz), fabsf(g.oz)), __fmul_rn((float)g.nz, g.cell))), 1.0e-7f);
@@ -403,43 +403,42 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
     int ry = y0, rz = grid_coord(__fsub_rn(q.pz, rzz), g.oz, g.inv, g.nz);
     const float rr2 = __fmul_rn(__fmul_rn(rr, rr), 1.0f + 1.0e-6f);
     const float huge = 3.0e38f;
-    // a lane whose walk is over (or that takes no part) has b = INT_MIN: "i < b" alone then says "has a point to test"
+    // Row advance WITHOUT divergent control flow (round 4): written with nested ifs (if (need) { if (rz > z1) .. else { .. if (rem
+    // >= 0) .. } }, rounds 1-3) it compiled to ~35 scalar instructions per trip - exec-mask saves and restores, the live booleans
+    // as scalar masks - on a scalar unit that sixteen waves share: 4.31 -> 4.19 ms for the kernel (profiles/r04_salu_diet_ab.txt).
+    // Here "needs a row" is (i >= b && rz <= z1) - a lane whose walk is over, or that takes no part, has rz beyond z1 and
+    // b = INT_MIN - every lane computes the row's range, and selects decide who takes it: one ballot per trip.
     int i = 0, b = act ? 0 : (-0x7fffffff - 1);
-    bool more = act;
+    if (!act) rz = z1 + 1;
+    bool more = act;   // (only read by the loop exit below)
     for (;;) {
-        // A: every lane that has used up its range advances to its next row with a non-empty range
-        bool need = more && i >= b;
-        while (ballot64(need)) {
+        for (;;) {
+            const bool adv = i >= b && rz <= z1;
+            if (!ballot64(adv)) break;
 #ifdef CD_STATS
-            { const unsigned long long nb_ = ballot64(need); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
+            { const unsigned long long nb_ = ballot64(adv); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
 #endif
-            if (need) {
-                if (rz > z1) {
-                    more = false;
-                    need = false;
-                    b = -0x7fffffff - 1;
-                } else {
-                    // slab of row (ry, rz); the outermost cells are open-ended (they also hold whatever rounding put past the box)
-                    const float ylo = ry == 0 ? -huge : __fadd_rn(g.oy, __fmul_rn((float)ry, g.cell));
-                    const float yhi = ry == g.ny - 1 ? huge : __fadd_rn(g.oy, __fmul_rn((float)(ry + 1), g.cell));
-                    const float zlo = rz == 0 ? -huge : __fadd_rn(g.oz, __fmul_rn((float)rz, g.cell));
-                    const float zhi = rz == g.nz - 1 ? huge : __fadd_rn(g.oz, __fmul_rn((float)(rz + 1), g.cell));
-                    const float ey = fmaxf(__fsub_rn(fmaxf(__fsub_rn(ylo, q.py), __fsub_rn(q.py, yhi)), sly), 0.f);
-                    const float ez = fmaxf(__fsub_rn(fmaxf(__fsub_rn(zlo, q.pz), __fsub_rn(q.pz, zhi)), slz), 0.f);
-                    const float e2 = __fmul_rn(__fadd_rn(__fmul_rn(ey, ey), __fmul_rn(ez, ez)), 1.0f - 1.0e-6f);
-                    const float rem = __fsub_rn(rr2, e2);
-                    if (rem >= 0.f) {
-                        // (a bound, not a result: the hardware square root is within 1 ulp, far inside the 1e-6 margin)
-                        const float rx = __fadd_rn(__fmul_rn(__builtin_amdgcn_sqrtf(rem), 1.0f + 1.0e-6f), slx);
-                        const int row = (rz * g.ny + ry) * g.nx;
-                        i = s_cs[row + grid_coord(__fsub_rn(q.px, rx), g.ox, g.inv, g.nx)];
-                        b = s_cs[row + grid_coord(__fadd_rn(q.px, rx), g.ox, g.inv, g.nx) + 1];
-                    }
-                    if (++ry > y1) { ry = y0; ++rz; }
-                    need = i >= b;
-                }
-            }
+            const int cz = min(rz, g.nz - 1);   // (address arithmetic of lanes that are done stays inside the table)
+            const float ylo = ry == 0 ? -huge : __fadd_rn(g.oy, __fmul_rn((float)ry, g.cell));
+            const float yhi = ry == g.ny - 1 ? huge : __fadd_rn(g.oy, __fmul_rn((float)(ry + 1), g.cell));
+            const float zlo = cz == 0 ? -huge : __fadd_rn(g.oz, __fmul_rn((float)cz, g.cell));
+            const float zhi = cz == g.nz - 1 ? huge : __fadd_rn(g.oz, __fmul_rn((float)(cz + 1), g.cell));
+            const float ey = fmaxf(__fsub_rn(fmaxf(__fsub_rn(ylo, q.py), __fsub_rn(q.py, yhi)), sly), 0.f);
+            const float ez = fmaxf(__fsub_rn(fmaxf(__fsub_rn(zlo, q.pz), __fsub_rn(q.pz, zhi)), slz), 0.f);
+            const float e2 = __fmul_rn(__fadd_rn(__fmul_rn(ey, ey), __fmul_rn(ez, ez)), 1.0f - 1.0e-6f);
+            const float rem = __fsub_rn(rr2, e2);
+            const bool hit = adv && rem >= 0.f;
+            const float rx = __fadd_rn(__fmul_rn(__builtin_amdgcn_sqrtf(fmaxf(rem, 0.f)), 1.0f + 1.0e-6f), slx);
+            const int row = (cz * g.ny + ry) * g.nx;
+            const int ni = s_cs[row + grid_coord(__fsub_rn(q.px, rx), g.ox, g.inv, g.nx)];
+            const int nb = s_cs[row + grid_coord(__fadd_rn(q.px, rx), g.ox, g.inv, g.nx) + 1];
+            i = hit ? ni : i;
+            b = hit ? nb : b;
+            const bool wrap = ry >= y1;
+            rz = (adv && wrap) ? rz + 1 : rz;
+            ry = adv ? (wrap ? y0 : ry + 1) : ry;
         }
+        more = i < b;
         if (!ballot64(more)) break;
         // B: test the points of the current ranges, two per trip.  No lane is switched off: a lane whose range is used up (or
         // whose walk is over) simply tests the points that follow it - real template points, which can never displace the true
@@ -490,7 +489,7 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
         }
     }
     const unsigned lo = (unsigned)(lkey & 0xffffffffull);
-    if (act && lo != KeyFmt<SH>::NONE) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & KeyFmt<SH>::POS_MASK); q.poi = PK ? (int)lo : (int)(lo >> SH); }
+    if (act && lo != KeyFmt<SH>::NONE) { q.pbest = __uint_as_float((unsigned)(lkey >> 32)); q.pbi = (int)(lo & KeyFmt<SH>::POS_MASK); q.poi = SK ? (int)lo : (int)(lo >> SH); }
 }
 
 // Search the staged chunk for the queries of this wave whose bit is set in `todo` (wave-uniform); updates q in place.
@@ -719,12 +718,14 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
     const int lane = threadIdx.x & 63;
     while (todo) {
         const int k = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
+        todo = clear_bit64(todo, k);
         const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
         const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
         const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
         const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-        const unsigned long long bound = ((unsigned long long)__float_as_uint(best) << 32) | 0xffffffffull;
+        // the query's seed key, as in far_begin: d2(q, seed) exactly and the seed's key word - a query whose neighbour does not
+        // change is done after its visits
+        const unsigned long long bound = ((unsigned long long)__float_as_uint(best) << 32) | (unsigned long long)(unsigned)__builtin_amdgcn_readlane(q.poi, k);
         unsigned long long lkey = bound;
         unsigned long long ma = ballot64(box_lb(sp.L, sp.H, x, y, z) <= best);
 #ifdef CD_STATS
@@ -732,7 +733,7 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
 #endif
         while (ma) {
             const int sidx = __ffsll((long long)ma) - 1;
-            ma &= ma - 1;
+            ma = clear_bit64(ma, sidx);
             const int first = __builtin_amdgcn_readlane(sp.first, sidx), cnt = __builtin_amdgcn_readlane(sp.cnt, sidx);
             const int pl = first + min(lane, cnt - 1);
             unsigned long long mp = ballot64(lane < cnt && box_lb(s_plo[pl], s_phi[pl], x, y, z) <= best);
@@ -740,10 +741,11 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
             if (lane == 0) atomicAdd(&g_icp_stats[1], (unsigned long long)__popcll(mp));
 #endif
             while (mp) {   // two patches per trip: their loads are in flight together (an odd one out is read twice)
-                const int r0 = first + __ffsll((long long)mp) - 1;
-                mp &= mp - 1;
-                const int r1 = mp ? first + __ffsll((long long)mp) - 1 : r0;
-                mp &= mp - 1;
+                const int b0 = __ffsll((long long)mp) - 1;
+                mp = clear_bit64(mp, b0);
+                const int b1 = mp ? __ffsll((long long)mp) - 1 : b0;
+                mp = clear_bit64(mp, b1);          // (clearing a bit that is already clear changes nothing)
+                const int r0 = first + b0, r1 = first + b1;
                 const float4 t = tplk[(unsigned)(r0 * ICP_SUB + lane)];
                 const float4 u = tplk[(unsigned)(r1 * ICP_SUB + lane)];
                 const unsigned pt = kdmap[(unsigned)(r0 * ICP_SUB + lane)];
@@ -756,11 +758,11 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
                 lkey = ke_ < lkey ? ke_ : lkey;
             }
         }
-        // minimum over the wave: as far_end (none / exactly one / several lanes beat the bound)
+        // minimum over the wave: as far_end (none - the neighbour stays - / exactly one / several lanes beat the seed key)
         const unsigned long long imp = ballot64(lkey < bound);
         if (imp == 0ull) continue;
         unsigned long long res;
-        if ((imp & (imp - 1ull)) == 0ull) {
+        if (__popcll(imp) == 1) {
             const int src = __ffsll((long long)imp) - 1;
             const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(lkey >> 32), src);
             const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)lkey, src);
@@ -774,7 +776,7 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
         const unsigned lo = (unsigned)res;
         q.pbest = mine ? __uint_as_float((unsigned)(res >> 32)) : q.pbest;
         q.pbi = mine ? (int)(lo & 0xffffu) : q.pbi;
-        q.poi = mine ? (int)(lo >> 16) : q.poi;
+        q.poi = mine ? (int)lo : q.poi;
     }
 }
 
@@ -1701,6 +1703,10 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #endif
                     QueryRegs q;
                     q.px = q.py = q.pz = q.pbest = 0.f; q.pbi = 0; q.poi = 0x7fffffff;
+                    // key word of the seed point: what the LDS image holds in .z, (original index << 16) | position for a
+                    // template in global memory; "no index" while there is no seed
+                    constexpr unsigned KW_NONE = BIG ? 0xffffffffu : 0x7fffffffu;
+                    unsigned kw = KW_NONE;
                     if (lane < nk) {
                         const float4 p = pts[myq];
                         if (phase == PH_ITER) {
@@ -1714,12 +1720,13 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                                 q.pbi = nnq[myq];
                                 const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                                 q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, BIG ? q0p.z : q0p.w);
+                                kw = BIG ? (((unsigned)__float_as_int(q0p.w) << 16) | (unsigned)q.pbi) : (unsigned)__float_as_int(q0p.z);
                             }
                             if (it < 3) {   // coarse seeds: first point of every run
                                 for (int j = 0; j < tpl_m; j += ICP_SUB) {
                                     const float4 t = BIG ? tp[j] : s_tpl[j];
                                     const float d = dist2(q.px, q.py, q.pz, t.x, t.y, BIG ? t.z : t.w);
-                                    if (d < q.pbest) { q.pbest = d; q.pbi = j; }
+                                    if (d < q.pbest) { q.pbest = d; q.pbi = j; kw = BIG ? (((unsigned)__float_as_int(t.w) << 16) | (unsigned)j) : (unsigned)__float_as_int(t.z); }
                                 }
                             }
                             q.pbest = seed_bound(q.pbest);
@@ -1736,24 +1743,23 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                             q.pbi = nnq[myq];
                             const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                             q.pbest = seed_bound(dist2(q.px, q.py, q.pz, q0p.x, q0p.y, BIG ? q0p.z : q0p.w));
-                            q.poi = __float_as_int(q0p.w);
+                            kw = BIG ? (((unsigned)__float_as_int(q0p.w) << 16) | (unsigned)q.pbi) : (unsigned)__float_as_int(q0p.z);
                         }
                     }
                     CD_PHASE(1)
                     float rr = 0.f;
                     bool near = false;
                     if (lane < nk) { rr = __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f); near = rr <= rmax; }
-                    if constexpr (!BIG) {
+                    {
                         // from the seed BOUND (next float above d2(q, seed): what the radius of the walk is derived from) to the
                         // seed's own KEY for both searches: d2 exactly (the bound's bit pattern minus one) and the key word of the
                         // seed point; a query without a finite seed distance keeps (+inf, no index)
                         const unsigned bb = __float_as_uint(q.pbest);
                         const bool fin = bb < 0x7f800000u && lane < nk;
-                        const unsigned kw = fin ? (unsigned)__float_as_int(s_tpl[q.pbi].z) : 0x7fffffffu;
                         q.pbest = __uint_as_float(fin ? bb - 1u : bb);
-                        q.poi = (int)kw;
+                        q.poi = (int)(fin ? kw : KW_NONE);
                     }
-                    if (ballot64(near)) grid_search<KSH, !BIG>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
+                    if (ballot64(near)) grid_search<KSH, !BIG, true>(BIG ? tp : s_tpl, s_cs, g, near, rr, q, gpad);
 #ifdef CD_STATS
                     { const unsigned long long nb_ = ballot64(near); if (lane == 0) { atomicAdd(&g_icp_stats[0], (unsigned long long)nk); atomicAdd(&g_icp_stats[3], (unsigned long long)__popcll(nb_)); } }
                     if (lane < nk && !near && phase == PH_ITER)

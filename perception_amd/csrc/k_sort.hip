@@ -96,7 +96,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_ghist(const uint32_t* __re
 
 __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __restrict__ kin, const uint32_t* __restrict__ vin,
                                                          uint32_t* __restrict__ kout, uint32_t* __restrict__ vout, int N,
-                                                         int T, int Tact, int pass, FrameState* __restrict__ fs,
+                                                         int T, int Tact, int pass, int shift, FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ ghist, int* __restrict__ state,
                                                          KeyPack kp, int use_runs, int* __restrict__ ticket) {
     __shared__ int s_ticket;
@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
     __shared__ uint32_t s_ws[RADIX / WAVE], s_gs[RADIX / WAVE];
     // workgroup b works on frame b % F and takes its tile by ticket (see k_crop_fused): a tile's predecessors in the chained
     // scan are long done
-    const int F = gridDim.x / Tact, shift = pass * RADIX_BITS;
+    const int F = gridDim.x / Tact;   // (pass: row of the frame's histogram table; shift: bit position of the digit)
     const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = use_runs ? fs[f].n_runs : fs[f].n_c;   // (runs: the elements are k_voxel_runs' (voxel index, start | length) pairs)
     if (tile * SORT_TILE >= n) return;
@@ -232,7 +232,7 @@ int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val
     int cur = 0;
     for (int pass = 0; pass < npass; ++pass) {
         hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], pass ? val[cur] : nullptr, key[cur ^ 1],
-                           val[cur ^ 1], N, Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 0, ticket);
+                           val[cur ^ 1], N, Tact, Tact, pass, pass * RADIX_BITS, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 0, ticket);
         kp.enabled = 0;   // later passes read voxel indices
         cur ^= 1;
     }
@@ -342,7 +342,24 @@ int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* cons
     int cur = 1;
     for (int pass = 0; pass < npass; ++pass) {
         hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], val[cur], key[cur ^ 1], val[cur ^ 1], N,
-                           Tact, Tact, pass, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 1, ticket);
+                           Tact, Tact, pass, pass * RADIX_BITS, fs, ghist, state + (size_t)pass * F * Tact * RADIX, kp, 1, ticket);
+        cur ^= 1;
+    }
+    return cur;
+}
+
+// The scatters of a sort whose run records and histograms k_crop_runs has already written (key[0] / val[0], ghist): one pass
+// per digit of the packed key that varies in some frame, lowest first.  `state` [ndigits][F][Tact][RADIX] is zeroed here.
+int launch_radix_scatter_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, const int* digits, int ndigits,
+                              FrameState* fs, const uint32_t* ghist, int* state, int* ticket) {
+    if (ndigits <= 0) return 0;
+    if (hipMemsetAsync(state, 0, sizeof(int) * (size_t)ndigits * F * Tact * RADIX, s) != hipSuccess) return -1;
+    KeyPack none;
+    none.enabled = 0; none.bi = none.bj = 0; none.ilo = none.jlo = none.klo = 0;
+    int cur = 0;
+    for (int q = 0; q < ndigits; ++q) {
+        hipLaunchKernelGGL(k_radix_scatter, dim3(Tact * F), dim3(SORT_BLOCK), 0, s, key[cur], val[cur], key[cur ^ 1], val[cur ^ 1], N,
+                           Tact, Tact, digits[q], digits[q] * RADIX_BITS, fs, ghist, state + (size_t)q * F * Tact * RADIX, none, 1, ticket);
         cur ^= 1;
     }
     return cur;

@@ -123,6 +123,18 @@ __global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, 
 }
 
 // ---- voxel grid geometry from the min/max (VoxelGrid::applyFilter prologue) ------------
+// after k_crop_runs: digit d of the packed cell keys varies in a frame when its histogram has two non-empty bins.  One wave per
+// frame, four coalesced 256-byte reads per digit.
+__global__ void __launch_bounds__(WAVE) k_digit_vary(FrameState* __restrict__ fs, const uint32_t* __restrict__ ghist) {
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int vary = 0;
+    for (int d = 0; d < 4; ++d) {
+        int bins = 0;
+        for (int q = 0; q < RADIX / WAVE; ++q) bins += __popcll(__ballot(ghist[((size_t)f * 4 + d) * RADIX + q * WAVE + lane] != 0u));
+        if (bins > 1) vary |= 1 << d;
+    }
+    if (lane == 0) fs[f].digit_vary = vary;
+}
 __global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
@@ -149,7 +161,7 @@ __global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
         cells *= (long long)(hi - lo + 1);
         if (cells > 2147483647ll) bad = true;
     }
-    if (bad) { s.status = CD_ERR_LEAF_TOO_SMALL; s.n_c = 0; return; }
+    if (bad) { s.status = CD_ERR_LEAF_TOO_SMALL; s.n_c = 0; s.n_runs = 0; return; }   // (n_runs: what k_crop_runs' sort and centroids go by)
     int bits = 1;
     while (bits < 31 && (1ll << bits) < cells) ++bits;
     s.key_bits = bits;
@@ -299,6 +311,151 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
         pos += __popcll(bal[j]);
     }
     if (__ballot(over) != 0ull && lane == 0) fs[f].crop_overflow = 1;
+}
+
+
+// ---- single pass, round 4: crop + ordered compaction + min/max + the RUNS and their digit histograms ------------------------
+// k_crop_fused wrote a 4-byte cell key per kept point and k_voxel_runs read them all back to find the runs of equal voxel
+// index, turn the keys into PCL's idx = i + j dx + k dx dy and build the sort's histograms.  None of that needs a second
+// pass: two neighbouring kept points are in one voxel exactly when their packed cell keys are equal, and the packed key
+// (x | y << bi | z << (bi + bj), every field a monotone function of its coordinate) orders the voxels exactly as idx does
+// (k, then j, then i) - so the SORT can run on the packed keys themselves, whose digits are known right here.  This kernel
+// therefore writes the kept points (16 bytes each), ONE record per run - (packed key, start | length << 20), a run being
+// consecutive kept points of one row of 64 input points with equal keys - and adds the runs' digits to the frame's four
+// histograms; which of the four digits vary at all, k_voxel_setup reads off those histograms afterwards (the y field is wide
+// because y is unbounded, but a frame's y cells span a few hundred values: digit 2 is constant unless they straddle a 512-cell
+// block - the host biases the field so that they do not).
+// Dropped: 4 bytes written per kept point, k_voxel_runs (a read of those keys, 0.12 ms), the key conversion in the first
+// scatter.  The chained scan carries both running counts (points, runs) in one 64-bit word.
+constexpr int RUN_SHIFT_C = 20;   // as k_sort.hip's RUN_SHIFT: start < 2^20, length <= 64
+__global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in, size_t stride, int N, int pitch,
+                                                     int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
+                                                     FrameState* __restrict__ fs, unsigned long long* __restrict__ state,
+                                                     float4* __restrict__ cpt, uint32_t* __restrict__ rkeys, uint32_t* __restrict__ rvals,
+                                                     uint32_t* __restrict__ ghist, int* __restrict__ ticket) {
+    __shared__ int s_cnt[WAVES_PER_BLOCK], s_rcnt[WAVES_PER_BLOCK];
+    __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
+    __shared__ uint32_t s_h[4][RADIX];
+    __shared__ int s_excl, s_rexcl, s_ticket;
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int F = gridDim.x / Tin;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tin, &s_ticket);
+    for (int q = threadIdx.x; q < 4 * RADIX; q += BLOCK) (&s_h[0][0])[q] = 0;
+    const size_t fbase = (size_t)f * N;        // input records
+    const size_t obase = (size_t)f * pitch;    // internal arrays
+    const int base = tile * TILE + w * WAVE_SPAN;
+    const float inv = __fdiv_rn(1.0f, leaf);
+    const float jlo = (float)kp.jlo, jhi = (float)(kp.jlo + ((1 << kp.bj) - 1));
+    float px[ITEMS], py[ITEMS], pz[ITEMS];
+    uint32_t pc[ITEMS], key[ITEMS];
+    uint64_t bal[ITEMS], heads[ITEMS];
+    int wtot = 0, rtot = 0;
+    float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
+    float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    bool over = false;
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const int e = base + j * WAVE + lane;
+        bool keep = false;
+        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0; key[j] = 0xffffffffu;
+        if (e < N) {
+            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
+            keep = crop_keep(px[j], py[j], pz[j], lim);
+            if (keep) {
+                mn[0] = fminf(mn[0], px[j]); mn[1] = fminf(mn[1], py[j]); mn[2] = fminf(mn[2], pz[j]);
+                mx[0] = fmaxf(mx[0], px[j]); mx[1] = fmaxf(mx[1], py[j]); mx[2] = fmaxf(mx[2], pz[j]);
+                const float fy = floorf(__fmul_rn(py[j], inv));
+                const bool fits = fy >= jlo && fy <= jhi;
+                over = over || !fits;
+                const uint32_t ui = (uint32_t)((int)floorf(__fmul_rn(px[j], inv)) - kp.ilo);
+                const uint32_t uj = fits ? (uint32_t)((int)fy - kp.jlo) : 0u;
+                const uint32_t uk = (uint32_t)((int)floorf(__fmul_rn(pz[j], inv)) - kp.klo);
+                key[j] = ui | (uj << kp.bi) | (uk << (kp.bi + kp.bj));
+            }
+        }
+        bal[j] = __ballot(keep);
+        // a run starts at a kept point whose left neighbour in the row is not kept or lies in another cell
+        const uint32_t prev = (uint32_t)__shfl_up((int)key[j], 1, 64);
+        const bool prev_kept = lane > 0 && ((bal[j] >> (lane - 1)) & 1ull);
+        heads[j] = __ballot(keep && !(prev_kept && prev == key[j]));
+        wtot += __popcll(bal[j]);
+        rtot += __popcll(heads[j]);
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            mn[a] = fminf(mn[a], __shfl_xor(mn[a], o, 64));
+            mx[a] = fmaxf(mx[a], __shfl_xor(mx[a], o, 64));
+        }
+    }
+    if (lane == 0) {
+        s_cnt[w] = wtot; s_rcnt[w] = rtot;
+        for (int a = 0; a < 3; ++a) { s_mn[w][a] = mn[a]; s_mx[w][a] = mx[a]; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0, rt = 0;
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) { tot += s_cnt[k]; rt += s_rcnt[k]; }
+        int excl = 0, rexcl = 0;
+        chained_scan2(state + (size_t)f * T, tile, tot, rt, &excl, &rexcl, &fs[f].crop_overflow);
+        s_excl = excl; s_rexcl = rexcl;
+        if (tile == Tin - 1) { fs[f].n_c = excl + tot; fs[f].n_runs = rexcl + rt; }
+        if (tot > 0) {
+            for (int a = 0; a < 3; ++a) {
+                float lo = s_mn[0][a], hi = s_mx[0][a];
+                for (int k = 1; k < WAVES_PER_BLOCK; ++k) { lo = fminf(lo, s_mn[k][a]); hi = fmaxf(hi, s_mx[k][a]); }
+                atomicMin(&fs[f].mn[a], f2ord(lo));
+                atomicMax(&fs[f].mx[a], f2ord(hi));
+            }
+        }
+    }
+    __syncthreads();
+    int pos = s_excl, rpos = s_rexcl;
+    for (int k = 0; k < w; ++k) { pos += s_cnt[k]; rpos += s_rcnt[k]; }
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        const bool kept = (bal[j] >> lane) & 1ull;
+        const int r = pos + __popcll(bal[j] & lt);
+        if (kept && r < pitch) cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
+        const bool is_head = (heads[j] >> lane) & 1ull;
+        if (is_head) {
+            // the run ends at the next head or at the first point of the row that is not kept, whichever comes first
+            const uint64_t stop = (~bal[j] | heads[j]) & (lane == 63 ? 0ull : ~((2ull << lane) - 1ull));
+            const int next = stop ? __ffsll((long long)stop) - 1 : 64;
+            const int ro = rpos + __popcll(heads[j] & lt);
+            if (ro < pitch) {
+                rkeys[obase + ro] = key[j];
+                rvals[obase + ro] = (uint32_t)r | ((uint32_t)(next - lane) << RUN_SHIFT_C);
+            }
+        }
+        // digit histograms of the run keys (as k_voxel_runs: above the lowest digit the heads of a row nearly always share the
+        // digit - one add of their number instead of that many adds to one LDS word)
+        if (heads[j]) {
+            const int first = __ffsll((long long)heads[j]) - 1;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const uint32_t d = (key[j] >> (p * RADIX_BITS)) & (RADIX - 1);
+                if (p > 0) {
+                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+                    if (__ballot(is_head && d != d0) == 0ull) {
+                        if (lane == first) atomicAdd(&s_h[p][d0], (uint32_t)__popcll(heads[j]));
+                        continue;
+                    }
+                }
+                if (is_head) atomicAdd(&s_h[p][d], 1u);
+            }
+        }
+        pos += __popcll(bal[j]);
+        rpos += __popcll(heads[j]);
+    }
+    if (__ballot(over) != 0ull && lane == 0) fs[f].crop_overflow = 1;
+    __syncthreads();
+    for (int q = threadIdx.x; q < 4 * RADIX; q += BLOCK) {
+        const uint32_t c = (&s_h[0][0])[q];
+        if (c) atomicAdd(&ghist[(size_t)f * 4 * RADIX + q], c);
+    }
 }
 
 // ---- voxel run heads in the sorted key array -------------------------------------------
@@ -520,7 +677,8 @@ void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int 
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch) {
     hipLaunchKernelGGL(k_scan_tiles, dim3(rows), dim3(BLOCK), 0, s, counts, T, totals, total_pitch);
 }
-void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf) {
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist) {
+    if (ghist) hipLaunchKernelGGL(k_digit_vary, dim3(F), dim3(WAVE), 0, s, fs, ghist);
     hipLaunchKernelGGL(k_voxel_setup, dim3((F + 63) / 64), dim3(64), 0, s, fs, F, leaf);
 }
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
@@ -534,6 +692,13 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
     const int Tin = (N + TILE - 1) / TILE;
     hipLaunchKernelGGL(k_crop_fused, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
                        leaf, kp, fs, state, cpt, keys, ticket);
+}
+void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                      int T, float leaf, KeyPack kp, FrameState* fs, unsigned long long* state, float4* cpt, uint32_t* rkeys,
+                      uint32_t* rvals, uint32_t* ghist, int* ticket) {
+    const int Tin = (N + TILE - 1) / TILE;
+    hipLaunchKernelGGL(k_crop_runs, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
+                       leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket);
 }
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {

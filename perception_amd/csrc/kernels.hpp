@@ -8,9 +8,12 @@ namespace cd {
 void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
                        FrameState* fs, int* tile_cnt);
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
-void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf);
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist = nullptr);
 void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                        int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket);
+void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
+                      int T, float leaf, KeyPack kp, FrameState* fs, unsigned long long* state, float4* cpt, uint32_t* rkeys,
+                      uint32_t* rvals, uint32_t* ghist, int* ticket);
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
@@ -28,6 +31,10 @@ constexpr int SORT_MAX_PASSES_HOST = 4;
 int launch_radix_sort(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, int npass,
                       FrameState* fs, uint32_t* ghist, int* state, KeyPack kp, int* ticket);
 // the same sort over RUNS of equal voxel index (k_voxel_runs: 2-3 x fewer elements on organised clouds); tile_state: [F][T] ints
+// the scatters alone, over run records whose digit histograms are already in ghist (k_crop_runs): `digits` lists the 8-bit digits
+// of the key that vary (ascending); the records are in key[0] / val[0]
+int launch_radix_scatter_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int Tact, const int* digits, int ndigits,
+                              FrameState* fs, const uint32_t* ghist, int* state, int* ticket);
 int launch_radix_sort_runs(hipStream_t s, uint32_t* const key[2], uint32_t* const val[2], int N, int F, int T, int Tact, int npass,
                            FrameState* fs, uint32_t* ghist, int* state, int* tile_state, KeyPack kp, int* ticket);
 

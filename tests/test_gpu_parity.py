@@ -585,15 +585,19 @@ def templates_small():
     return T.template_xyz32(length=0.2, width=0.075, height=0.1, density=0.005)
 
 
-@pytest.mark.parametrize("path", ["runs", "points", "runs_off_for_big_contexts"])
+@pytest.mark.parametrize("path", ["crop_runs", "runs", "points", "runs_off_for_big_contexts"])
 def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
-    """S1 sorts RUNS of equal voxel index among the cropped points by default (k_voxel_runs, k_voxel_centroid_runs);
-    CUBOID_VOXEL_RUNS=0 sorts the points (k_radix_ghist, k_voxel_centroid), and so does a context of more than 2^20 points per
-    frame (a run's start has 20 bits).  Same bits as the oracle either way, on: organised frames (runs of ~2.4 points), one
-    voxel holding 3000 consecutive points (runs are cut at every 64), keys that alternate from point to point (every run is
-    one point long), an unorganised cloud with rgb, frames in a batch."""
+    """S1 sorts RUNS of equal voxel index among the cropped points.  Default since round 4 ("crop_runs"): the crop itself
+    writes the runs and their digit histograms and the sort runs on the packed cell keys, only over the digits that vary
+    (k_crop_runs, k_voxel_centroid_runs); CUBOID_CROP_RUNS=0 ("runs"): the crop writes per-point keys and k_voxel_runs finds the
+    runs (rounds 2-3); CUBOID_VOXEL_RUNS=0 sorts the points (k_radix_ghist, k_voxel_centroid), and so does a context of more
+    than 2^20 points per frame (a run's start has 20 bits).  Same bits as the oracle either way, on: organised frames (runs of
+    ~2.4 points), one voxel holding 3000 consecutive points (runs are cut at every 64), keys that alternate from point to
+    point (every run is one point long), an unorganised cloud with rgb, frames in a batch."""
     if path == "points":
         monkeypatch.setenv("CUBOID_VOXEL_RUNS", "0")
+    if path == "runs":
+        monkeypatch.setenv("CUBOID_CROP_RUNS", "0")
     rng = np.random.RandomState(12)
     max_points = (1 << 20) + 4096 if path == "runs_off_for_big_contexts" else synth.WIDTH * synth.HEIGHT
     cx = capi.Context(max_points=max_points, max_frames=2)
