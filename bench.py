@@ -569,7 +569,7 @@ def main():
         # (3) BASELINE config 5: 1 M-point frames, five cuboids, five templates, every cluster against every template
         try:
             from perception_amd import synth
-            F5, M5, K5 = len(frames_c5), 4, 10
+            F5, M5, K5 = len(frames_c5), 4, 16
             tpl5 = {k: templates.template_xyz32(L, W, H, dd) for k, (L, W, H, dd) in enumerate(synth.CONFIG5_DIMS)}
             prm5 = capi.default_params()
             prm5.rgb_offset = 12
@@ -638,8 +638,11 @@ def main():
         head_ms = excl_ms if excl_ms is not None else avg_launch_ms
         head_achieved = per_launch_bytes / (head_ms * 1e-3) / 1e9
         timed_regime = None
-        if timings and timings[-1].icp_regime:
-            timed_regime = {"slots": timings[-1].icp_regime >> 16, "workgroups": timings[-1].icp_regime & 0xffff}
+        if timings:   # the shape most launches of the timed region had (the last ones, with the pipeline draining, fall back to 2 x 256)
+            import collections
+            reg, cnt = collections.Counter(t.icp_regime for t in timings if t.icp_regime).most_common(1)[0] if any(t.icp_regime for t in timings) else (0, 0)
+            if reg:
+                timed_regime = {"slots": reg >> 16, "workgroups": reg & 0xffff, "launches": cnt, "of": len(timings)}
         # What bounds the dominant kernel.  Its working set is LDS/L2-resident (traffic = 0.37 x algorithmic bytes), so HBM is not
         # its roof; the SQ counters (committed, collected by tools/profile_round4.sh on ONE launch alone: the regime of `achieved`)
         # are read against what the same counters show on a SATURATED vector pipe at the same launch shape
