@@ -13,6 +13,7 @@
 #include <atomic>
 #include <mutex>
 #include <shared_mutex>
+#include <condition_variable>
 #include <random>
 #include <vector>
 
@@ -88,6 +89,7 @@ struct cd_context {
     hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
                                                                   // first (stream2); with icp_lowprio both are low-priority streams, so that CUs that come free go to the
                                                                   // short front-end kernels of the other batches in flight before the next persistent workgroup
+    int icp_concurrent = 0;                                       // CUBOID_ICP_CONCURRENT: admission gate of the whole-cluster ICP launches (0 = none)
     int icp_lowprio = 1;                                          // CUBOID_ICP_LOWPRIO: 0 never, 1 the launches of a mixed-template batch (measured: config 5 +30 %), 2 every
                                                                   // persistent ICP launch (config 3: -1 %)
     hipEvent_t ev2[3] = {nullptr, nullptr, nullptr};
@@ -174,6 +176,19 @@ struct BatchGuard {  // (a cd_bbox_filter or cd_extract beside a batch must not 
     explicit BatchGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_batches_in_flight[dev].fetch_add(1); }
     ~BatchGuard() { g_batches_in_flight[dev].fetch_sub(1); }
 };
+// Admission gate of the whole-cluster ICP launches (CUBOID_ICP_CONCURRENT = K; 0 = none): at most K contexts of a device are
+// between the launch of their persistent ICP kernel and its completion.  The launches of several batches otherwise share the
+// CUs workgroup by workgroup (processor sharing: five batches submitted together all finish late, together); through the gate
+// they run K at a time, first come first served, so the first batches of a burst come back early and their contexts refill
+// the pipeline.
+struct IcpGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int inside = 0;
+    void enter(int k) { std::unique_lock<std::mutex> lk(mu); cv.wait(lk, [&] { return inside < k; }); ++inside; }
+    void leave() { { std::lock_guard<std::mutex> lk(mu); --inside; } cv.notify_one(); }
+};
+IcpGate g_icp_gate[MAX_DEVICES];
 struct CallGuard {   // one per compute call: counts the contexts at work on the device (k_icp_persist wants the chip to itself)
     int dev;
     explicit CallGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_calls_in_flight[dev].fetch_add(1); }
@@ -753,6 +768,11 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (whole_cluster) {
+        struct GateHold {   // (released on every path out of this block)
+            IcpGate* g = nullptr;
+            ~GateHold() { if (g) g->leave(); }
+        } hold;
+        if (c->icp_concurrent > 0) { hold.g = &g_icp_gate[c->device & (MAX_DEVICES - 1)]; hold.g->enter(c->icp_concurrent); }
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
@@ -1340,6 +1360,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_FORCE_SCAN_STALL")) c->force_stall = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_RUNS")) c->crop_runs = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_ICP_CONCURRENT")) c->icp_concurrent = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;

@@ -430,21 +430,26 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
                 rvals[obase + ro] = (uint32_t)r | ((uint32_t)(next - lane) << RUN_SHIFT_C);
             }
         }
-        // digit histograms of the run keys (as k_voxel_runs: above the lowest digit the heads of a row nearly always share the
-        // digit - one add of their number instead of that many adds to one LDS word)
+        // digit histograms of the run keys.  The heads of a row (64 neighbouring pixels) nearly always share everything above the
+        // lowest digit - the y and z cells and the high bit of x: ONE test per row decides that, and then one lane adds the
+        // row's head count to the three upper bins (adds to one LDS word would serialise; and a test per digit, as k_voxel_runs
+        // has it, is ~60 scalar instructions per row on a kernel that was HBM-bound before it carried them)
         if (heads[j]) {
             const int first = __ffsll((long long)heads[j]) - 1;
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const uint32_t d = (key[j] >> (p * RADIX_BITS)) & (RADIX - 1);
-                if (p > 0) {
-                    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
-                    if (__ballot(is_head && d != d0) == 0ull) {
-                        if (lane == first) atomicAdd(&s_h[p][d0], (uint32_t)__popcll(heads[j]));
-                        continue;
-                    }
+            const uint32_t up = key[j] >> RADIX_BITS;
+            const uint32_t up0 = (uint32_t)__builtin_amdgcn_readlane((int)up, first);
+            if (is_head) atomicAdd(&s_h[0][key[j] & (RADIX - 1)], 1u);
+            if (__ballot(is_head && up != up0) == 0ull) {
+                if (lane == first) {
+                    const uint32_t c = (uint32_t)__popcll(heads[j]);
+                    atomicAdd(&s_h[1][up0 & (RADIX - 1)], c);
+                    atomicAdd(&s_h[2][(up0 >> RADIX_BITS) & (RADIX - 1)], c);
+                    atomicAdd(&s_h[3][up0 >> (2 * RADIX_BITS)], c);
                 }
-                if (is_head) atomicAdd(&s_h[p][d], 1u);
+            } else if (is_head) {
+                atomicAdd(&s_h[1][up & (RADIX - 1)], 1u);
+                atomicAdd(&s_h[2][(up >> RADIX_BITS) & (RADIX - 1)], 1u);
+                atomicAdd(&s_h[3][up >> (2 * RADIX_BITS)], 1u);
             }
         }
         pos += __popcll(bal[j]);

@@ -83,3 +83,25 @@ def test_two_rank_gather_equals_single_process():
     assert got[0] == got[1] == ref          # every rank holds the whole batch, in frame order
     recs = capi.results_from_array(np.frombuffer(ref, np.uint8).reshape(NF, capi.FRAME_RESULT_BYTES))
     assert all(r.n_voxels > 0 for r in recs)
+
+
+def test_native_driver_argument_checks_without_a_gpu():
+    """perception_amd/cpp/cuboid_multi_gpu (the native frame-per-GPU driver: one thread + context per GPU, ncclAllGather of the
+    records) refuses, before it touches HIP or RCCL, a device list that puts two ranks on one device under RCCL, a list of the
+    wrong length and a missing input; its slicing rule is batch.shard_range's (checked on the GPU box against the Python driver:
+    tests/test_gpu_multi_native.py)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "perception_amd", "cpp", "cuboid_multi_gpu")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "perception_amd", "cpp"), "cuboid_multi_gpu"], check=True, stdout=subprocess.DEVNULL)
+    base = [exe, "--frames", "/nonexistent.bin", "--points", "10", "--template", "/nonexistent.pcd"]
+    r = subprocess.run(base + ["--gpus", "2", "--devices", "0,0"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "one device per rank" in r.stderr
+    r = subprocess.run(base + ["--gpus", "3", "--devices", "0,1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "names 2 devices for 3 ranks" in r.stderr
+    r = subprocess.run(base + ["--gpus", "1"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2          # no such frames file
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "usage:" in r.stderr
