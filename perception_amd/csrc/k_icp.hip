@@ -781,99 +781,6 @@ __device__ __forceinline__ void search_patches_big(const float4* __restrict__ tp
 }
 
 
-// ---------------------------------------------------------------------------------------
-// k_icp_pipe_big's far search as a list of (query, patch) pairs (round 4).  For a template in LDS the pair list lost to the
-// per-query loop (what a far query costs there is scalar work, and a list adds to it).  Here the points
-// come from GLOBAL memory: search_patches_big waits ~700 cycles for the patch reads of every query, one query after the
-// other.  So the box tests stay as they are (superpatch boxes in registers, patch boxes in LDS) but the surviving patches are
-// FILED - the lanes whose patch box passed write (query lane << 16 | patch) at list[np + mbcnt(mask)] - and visited later,
-// four pairs per trip with all eight global loads in flight together; candidates that beat their query's seed key lower the
-// query's LDS word (ds_min_u64: rule C5's lexicographic minimum is an unsigned 64-bit minimum of the keys, order-free), and
-// the query lanes read their words back at the end.  The drain is vector-only: the pair comes from a broadcast LDS read, the
-// query's coordinates through ds_bpermute.  Same candidates, same keys, same minimum: bit-identical.
-// LDS per wave: 64 words (one per query lane) + BIG_LIST pairs.
-// ---------------------------------------------------------------------------------------
-constexpr int BIG_LIST = 256;   // pairs per wave between two drains (a superpatch adds at most 64)
-
-__device__ __forceinline__ void big_drain(const float4* __restrict__ tplk, const unsigned short* __restrict__ kdmap, const QueryRegs& q,
-                                          const unsigned* list, int np, unsigned long long* slots) {
-    const int lane = threadIdx.x & 63;
-    for (int p = 0; p < np; p += 4) {
-        unsigned e[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) e[i] = list[p + i < np ? p + i : np - 1];   // (an odd one out is done again: the minimum does not mind)
-        float4 t[4];
-        unsigned pos[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const unsigned a = (e[i] & 0xffffu) * ICP_SUB + (unsigned)lane;
-            t[i] = tplk[a];
-            pos[i] = kdmap[a];
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int a = (int)((e[i] >> 16) << 2);   // byte address of the query lane's dword for ds_bpermute
-            const float x = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(q.px)));
-            const float y = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(q.py)));
-            const float z = __int_as_float(__builtin_amdgcn_ds_bpermute(a, __float_as_int(q.pz)));
-            const unsigned b = (unsigned)__builtin_amdgcn_ds_bpermute(a, __float_as_int(q.pbest));
-            const unsigned kw = (unsigned)__builtin_amdgcn_ds_bpermute(a, q.poi);
-            const float d = dist2(x, y, z, t[i].x, t[i].y, t[i].z);
-            const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (((unsigned)__float_as_int(t[i].w) << 16) | pos[i]);
-            if (key < (((unsigned long long)b << 32) | kw)) __hip_atomic_fetch_min(&slots[e[i] >> 16], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    }
-}
-
-__device__ __forceinline__ void search_pairs_big(const float4* __restrict__ tplk, const unsigned short* __restrict__ kdmap,
-                                                 const float4* s_plo, const float4* s_phi, const SuperRegs& sp, QueryRegs& q,
-                                                 unsigned long long todo, unsigned long long* slots, unsigned* list) {
-    const int lane = threadIdx.x & 63;
-    if (todo == 0ull) return;
-    const bool mine = (todo >> lane) & 1ull;
-    const unsigned long long seed = ((unsigned long long)__float_as_uint(q.pbest) << 32) | (unsigned long long)(unsigned)q.poi;
-    // every far query lane starts its word at its seed key (LDS operations of one wave execute in program order)
-    if (mine) __hip_atomic_store(&slots[lane], seed, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-    int np = 0;
-    while (todo) {
-        const int k = __ffsll((long long)todo) - 1;
-        todo = clear_bit64(todo, k);
-        const float x = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.px), k));
-        const float y = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.py), k));
-        const float z = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pz), k));
-        const float best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.pbest), k));
-        unsigned long long ma = ballot64(box_lb(sp.L, sp.H, x, y, z) <= best);
-#ifdef CD_STATS
-        if (lane == 0) atomicAdd(&g_icp_stats[2], 1ull);
-#endif
-        while (ma) {
-            const int sidx = __ffsll((long long)ma) - 1;
-            ma = clear_bit64(ma, sidx);
-            const int first = __builtin_amdgcn_readlane(sp.first, sidx), cnt = __builtin_amdgcn_readlane(sp.cnt, sidx);
-            const int pl = first + min(lane, cnt - 1);
-            const bool hit = lane < cnt && box_lb(s_plo[pl], s_phi[pl], x, y, z) <= best;
-            const unsigned long long mp = ballot64(hit);
-#ifdef CD_STATS
-            if (lane == 0) atomicAdd(&g_icp_stats[1], (unsigned long long)__popcll(mp));
-#endif
-            if (mp == 0ull) continue;
-            if (np + 64 > BIG_LIST) { big_drain(tplk, kdmap, q, list, np, slots); np = 0; }
-            if (hit) list[np + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mp >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mp, 0u))] = ((unsigned)k << 16) | (unsigned)(first + lane);
-            np += __popcll(mp);
-        }
-    }
-    if (np > 0) big_drain(tplk, kdmap, q, list, np, slots);
-    if (mine) {
-        const unsigned long long res = __hip_atomic_load(&slots[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-        if (res < seed) {
-            const unsigned lo = (unsigned)res;
-            q.pbest = __uint_as_float((unsigned)(res >> 32));
-            q.pbi = (int)(lo & 0xffffu);
-            q.poi = (int)lo;
-        }
-    }
-}
-
 __device__ __forceinline__ void store_queries(const QueryRegs& q, int nk, int* nn, float* d2buf) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (lane < nk) {
@@ -1684,8 +1591,6 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     __shared__ unsigned short s_kd[BIG ? 1 : ICPT_IMG];   // k-d patch order -> stored position (tlo/thi are the PATCH boxes)
     __shared__ unsigned long long s_far[ICPT_WAVES];   // one word per wave: the running minimum of the far query it is on
     __shared__ float4 s_plo[BIG ? ICP_BIG_PATCHES : 1], s_phi[BIG ? ICP_BIG_PATCHES : 1];   // BIG: boxes of all k-d patches
-    __shared__ unsigned long long s_bslot[BIG ? ICPT_WAVES * WAVE : 1];   // BIG: the far queries' running minima, one word per query lane and wave
-    __shared__ unsigned s_blist[BIG ? ICPT_WAVES * BIG_LIST : 1];         // BIG: the waves' (query, patch) pairs
     constexpr int KSH = BIG ? 16 : 13;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     // A workgroup keeps ONE (LDS-resident, gridded) template for its whole life.  With several templates in a launch
@@ -1863,11 +1768,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #endif
                     CD_PHASE(2)
                     if constexpr (BIG) {
-#ifdef CD_BIG_PER_QUERY
                         search_patches_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_far[wave]);
-#else
-                        search_pairs_big(tk, km, s_plo, s_phi, sp, q, ballot64(lane < nk && !near), &s_bslot[wave * WAVE], &s_blist[wave * BIG_LIST]);
-#endif
                     } else {
 #ifdef CD_ITSTATS
                     int stat_acc[2] = {0, 0};
