@@ -631,3 +631,31 @@ def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
                 assert res[f].n_voxels == len(want[f]) and np.array_equal(got.view(np.uint32), want[f].view(np.uint32))
     finally:
         cx.close()
+
+
+def test_crop_runs_sort_passes_follow_the_digits_that_vary(ctx, O):
+    """k_crop_runs' sort runs on the packed cell keys and only over the 8-bit digits that take more than one value in some
+    frame (k_digit_vary).  The bench frames need three; here: a cloud whose y cells span more than an aligned block of 512
+    (y in +-2 m at the 5 mm leaf: the digit above the ninth y bit varies - four passes), a cloud inside ONE voxel (no digit
+    varies - no pass at all), and one that differs in the x cell only (one pass).  Bits equal to the oracle's every time."""
+    rng = np.random.RandomState(21)
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+
+    def check(pts):
+        vox, rgb, nc = ctx.crop_voxel(pts, prm, want_rgb=True)
+        st, vo, ro, nco, _ = O.crop_voxel(pts, prm, want_rgb=True)
+        assert st == 0 and nc == nco and len(vox) == len(vo)
+        assert np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+        return len(vo)
+
+    wide = np.zeros((40000, 4), np.float32)
+    wide[:, :3] = rng.uniform([-0.19, -2.0, 0.05], [0.19, 2.0, 0.85], (40000, 3))
+    wide[:, 3] = rng.randint(0, 1 << 24, 40000).astype(np.uint32).view(np.float32)
+    assert check(wide) > 30000
+    one = np.zeros((777, 4), np.float32)
+    one[:, :3] = np.float32([0.101, 0.051, 0.501]) + rng.uniform(0, 0.0039, (777, 3)).astype(np.float32)
+    assert check(one) == 1
+    xonly = one.copy()
+    xonly[:, 0] += (np.arange(777) % 5).astype(np.float32) * np.float32(0.005)     # five neighbouring x cells, same y and z cell
+    assert check(xonly) == 5
