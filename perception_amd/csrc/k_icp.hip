@@ -409,19 +409,11 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
     // Here "needs a row" is (i >= b && rz <= z1) - a lane whose walk is over, or that takes no part, has rz beyond z1 and
     // b = INT_MIN - every lane computes the row's range, and selects decide who takes it: one ballot per trip.
     int i = 0, b = act ? 0 : (-0x7fffffff - 1);
-#ifdef CD_WALK_TWO
-    int i2 = 0, b2 = 0;   // a second range per lane: the point loop moves on to it without waiting for the next row advance
-#endif
     if (!act) rz = z1 + 1;
     bool more = act;   // (only read by the loop exit below)
     for (;;) {
         for (;;) {
-#ifdef CD_WALK_TWO
-            const bool empty1 = i >= b;
-            const bool adv = (empty1 || i2 >= b2) && rz <= z1;
-#else
             const bool adv = i >= b && rz <= z1;
-#endif
             if (!ballot64(adv)) break;
 #ifdef CD_STATS
             { const unsigned long long nb_ = ballot64(adv); if ((threadIdx.x & 63) == 0) { atomicAdd(&g_icp_stats[4], 1ull); atomicAdd(&g_icp_stats[5], (unsigned long long)__popcll(nb_)); } }
@@ -440,16 +432,8 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
             const int row = (cz * g.ny + ry) * g.nx;
             const int ni = s_cs[row + grid_coord(__fsub_rn(q.px, rx), g.ox, g.inv, g.nx)];
             const int nb = s_cs[row + grid_coord(__fadd_rn(q.px, rx), g.ox, g.inv, g.nx) + 1];
-#ifdef CD_WALK_TWO
-            const bool full = hit && ni < nb, to1 = full && empty1, to2 = full && !empty1;
-            i = to1 ? ni : i;
-            b = to1 ? nb : b;
-            i2 = to2 ? ni : i2;
-            b2 = to2 ? nb : b2;
-#else
             i = hit ? ni : i;
             b = hit ? nb : b;
-#endif
             const bool wrap = ry >= y1;
             rz = (adv && wrap) ? rz + 1 : rz;
             ry = adv ? (wrap ? y0 : ry + 1) : ry;
@@ -501,15 +485,6 @@ __device__ __forceinline__ void grid_search(const float4* s_tpl, const unsigned 
             lkey = kd_ < lkey ? kd_ : lkey;
             lkey = ke_ < lkey ? ke_ : lkey;
             i += 2;
-#ifdef CD_WALK_TWO
-            {   // this range used up and a second one waiting: take it
-                const bool sw = i >= b && i2 < b2;
-                i = sw ? i2 : i;
-                b = sw ? b2 : b;
-                b2 = sw ? 0 : b2;
-                i2 = sw ? 0 : i2;
-            }
-#endif
             }
         }
     }
