@@ -169,6 +169,20 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o) {
 // wave ballot of a BOOL: HIP's __ballot(int) first turns a lane mask that is already in SGPRs (e.g. a && of two compares)
 // into a 0/1 vector and compares it again - two vector instructions per loop condition in the ICP search loops
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// R rows of a wave's tile, ALL loaded before any is used: element first + j * 64 of an array of n >= 1 elements, the index
+// clamped into the array instead of tested (callers still ignore rows past n).  A load inside `if (e < n)` is followed by
+// s_waitcnt vmcnt(0) before the next row's load is even issued - one memory round trip per row, eight in a row
+// (tools/isa_load_pattern.py shows which kernels have that shape).
+template <int R, typename T>
+__device__ __forceinline__ void load_rows_clamped(const T* __restrict__ a, int first, int n, T (&v)[R]) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        int e = first + j * WAVE;
+        e = e < n ? e : n - 1;
+        v[j] = a[e < 0 ? 0 : e];
+    }
+}
+
 __device__ __forceinline__ uint64_t lanemask_lt() {
     const uint32_t lane = threadIdx.x & 63;
     return (lane == 0) ? 0ull : (~0ull >> (64 - lane));

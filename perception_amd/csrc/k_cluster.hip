@@ -287,11 +287,12 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __rest
     float4 pt[CL_PER_THREAD];
     int sl[CL_PER_THREAD], tk[CL_PER_THREAD];
 #pragma unroll
+    for (int k = 0; k < CL_PER_THREAD; ++k) pt[k] = P[min(tid + k * CL_THREADS, n - 1)];   // (all loads first: see load_rows_clamped)
+#pragma unroll
     for (int k = 0; k < CL_PER_THREAD; ++k) {
         const int i = tid + k * CL_THREADS;
         sl[k] = 0; tk[k] = 0;
         if (i < n) {
-            pt[k] = P[i];
             int cx, cy, cz;
             cell_of(pt[k], org, inv_cell, cx, cy, cz);
             bool ok = cx >= CL_COORD_MIN && cy >= CL_COORD_MIN && cz >= CL_COORD_MIN && cx <= CL_COORD_MAX && cy <= CL_COORD_MAX && cz <= CL_COORD_MAX;
@@ -474,12 +475,22 @@ __global__ void __launch_bounds__(BLOCK) k_label_count(int N, int T, const Frame
     int cnt[KICP];
 #pragma unroll
     for (int k = 0; k < KICP; ++k) cnt[k] = 0;
+    // (all parents, then all ranks, before any is used: two memory round trips instead of sixteen - see load_rows_clamped)
+    int rt[ITEMS];
+    if (enable) {
+        load_rows_clamped<ITEMS>(parent + fbase, base, n, rt);
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) rt[j] = rank_of_root[fbase + rt[j]];
+    } else {
+#pragma unroll
+        for (int j = 0; j < ITEMS; ++j) rt[j] = 0;
+    }
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         int lab = -1;
         if (e < n) {
-            lab = enable ? rank_of_root[fbase + parent[fbase + e]] : 0;
+            lab = rt[j];
             if (kbase == 0) label[fbase + e] = lab;
         }
 #pragma unroll
@@ -512,10 +523,13 @@ __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restric
     int cnt[KICP];
 #pragma unroll
     for (int k = 0; k < KICP; ++k) cnt[k] = 0;
+    float4 pr[ITEMS];
+    load_rows_clamped<ITEMS>(label + fbase, base, n, lab);   // (labels and points of all rows before any is used)
+    load_rows_clamped<ITEMS>(obj + fbase, base, n, pr);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
-        lab[j] = e < n ? label[fbase + e] - kbase : -1;   // rank within the round (other rounds' clusters fall outside 0..KICP-1)
+        lab[j] = e < n ? lab[j] - kbase : -1;   // rank within the round (other rounds' clusters fall outside 0..KICP-1)
 #pragma unroll
         for (int k = 0; k < KICP; ++k) cnt[k] += __popcll(__ballot(lab[j] == k));
     }
@@ -534,12 +548,11 @@ __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restric
     const uint64_t lt = lanemask_lt();
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
-        const int e = base + j * WAVE;
 #pragma unroll
         for (int k = 0; k < KICP; ++k) {
             const uint64_t bal = __ballot(lab[j] == k);
             if (lab[j] == k) {
-                const float4 p = obj[fbase + e];
+                const float4 p = pr[j];
                 const int d = pos[k] + __popcll(bal & lt);
                 src0[fbase + d] = p;
                 src[fbase + d] = p;

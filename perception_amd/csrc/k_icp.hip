@@ -1708,6 +1708,15 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     // template in global memory; "no index" while there is no seed
                     constexpr unsigned KW_NONE = BIG ? 0xffffffffu : 0x7fffffffu;
                     unsigned kw = KW_NONE;
+#ifdef CD_TIMERS_FETCH
+                    {   // how long a wave waits for its pass's points and neighbour indices (the loads below then hit L1)
+                        float4 pp = make_float4(0.f, 0.f, 0.f, 0.f);
+                        int nv = 0;
+                        if (lane < nk) { pp = pts[myq]; nv = nnq[myq]; }
+                        asm volatile("s_waitcnt vmcnt(0)" ::"v"(pp.x), "v"(nv) : "memory");
+                        CD_PHASE(3)
+                    }
+#endif
                     if (lane < nk) {
                         const float4 p = pts[myq];
                         if (phase == PH_ITER) {

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(BLOCK) k_ransac_count(const float4* __restrict
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         in[j] = e < n;
-        const float4 p = in[j] ? P[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 p = P[e < n ? e : n - 1];   // (clamped, not tested: the eight loads go out together)
         px[j] = p.x; py[j] = p.y; pz[j] = p.z;
     }
     const float4* M = models + (size_t)f * MAX_HYP;
@@ -140,11 +140,13 @@ __global__ void __launch_bounds__(BLOCK) k_plane_cov(const float4* __restrict__ 
     const float4* P = vox + (size_t)f * N;
     const int base = tile * TILE + w * WAVE_SPAN + lane;
     unsigned long long S[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float4 pr[ITEMS];
+    load_rows_clamped<ITEMS>(P, base, n, pr);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         if (e < n) {
-            const float4 p = P[e];
+            const float4 p = pr[j];
             if (plane_inlier(m, 1, thr, p)) {
                 S[0] += (unsigned long long)fixq(__fmul_rn(p.x, p.x), FIX_SHIFT);
                 S[1] += (unsigned long long)fixq(__fmul_rn(p.x, p.y), FIX_SHIFT);
@@ -204,11 +206,13 @@ __global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __rest
     const float4* P = vox + (size_t)f * N;
     const int base = tile * TILE + w * WAVE_SPAN + lane;
     int ca = 0, cb = 0;
+    float4 pr[ITEMS];
+    load_rows_clamped<ITEMS>(P, base, n, pr);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         bool inl = false, obj = false;
-        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, P[e], inl, obj);
+        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, pr[j], inl, obj);
         ca += __popcll(__ballot(inl));
         cb += __popcll(__ballot(obj));
     }
@@ -238,15 +242,12 @@ __global__ void __launch_bounds__(BLOCK) k_extract_scatter(const float4* __restr
     float4 p[ITEMS];
     uint64_t ba[ITEMS], bb[ITEMS];
     int ca = 0, cb = 0;
+    load_rows_clamped<ITEMS>(P, base, n, p);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE;
         bool inl = false, obj = false;
-        p[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (e < n) {
-            p[j] = P[e];
-            extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, p[j], inl, obj);
-        }
+        if (e < n) extract_flags(m, hv, thr, negative, crop2, z2lo, z2hi, gate, p[j], inl, obj);
         ba[j] = __ballot(inl);
         bb[j] = __ballot(obj);
         ca += __popcll(ba[j]);
@@ -307,10 +308,12 @@ __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;
+    int fl[ITEMS];
+    load_rows_clamped<ITEMS>(flag, base + lane, n, fl);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE + lane;
-        bal[j] = ballot64(e < n && flag[e] == 0);
+        bal[j] = ballot64(e < n && fl[j] == 0);
         wtot += __popcll(bal[j]);
     }
     if (lane == 0) s_cnt[w] = wtot;

@@ -14,17 +14,28 @@
 
 namespace cd {
 
-__device__ __forceinline__ void load_point(const char* __restrict__ in, size_t stride, size_t idx, int rgb_off,
-                                           float& x, float& y, float& z, uint32_t& rgb) {
-    const char* p = in + idx * stride;
+// ALL rows of a wave, loaded before any of them is used.  Written as "load a row, test it, load the next" (rounds 1-4: the load
+// sat inside `if (e < N)`) every row's load was followed by s_waitcnt vmcnt(0) - a wave paid one memory round trip per row,
+// eight in a row, and the crop moved its bytes at 4.2 TB/s only by keeping many waves resident.  Here the index is clamped
+// instead of tested (the caller still ignores rows past N) and the record format is decided once, outside the loop.
+template <int R>
+__device__ __forceinline__ void load_rows(const char* __restrict__ in, size_t stride, size_t fbase, int first, int N, int rgb_off,
+                                          float (&x)[R], float (&y)[R], float (&z)[R], uint32_t (&rgb)[R]) {
     if (stride == 16 && rgb_off == 12) {
-        const float4 v = *reinterpret_cast<const float4*>(p);
-        x = v.x; y = v.y; z = v.z; rgb = __float_as_uint(v.w);
+        float4 v[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) v[j] = *reinterpret_cast<const float4*>(in + (fbase + (size_t)min(first + j * WAVE, N - 1)) * 16);
+#pragma unroll
+        for (int j = 0; j < R; ++j) { x[j] = v[j].x; y[j] = v[j].y; z[j] = v[j].z; rgb[j] = __float_as_uint(v[j].w); }
     } else {
-        x = *reinterpret_cast<const float*>(p);
-        y = *reinterpret_cast<const float*>(p + 4);
-        z = *reinterpret_cast<const float*>(p + 8);
-        rgb = rgb_off >= 0 ? *reinterpret_cast<const uint32_t*>(p + rgb_off) : 0u;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const char* p = in + (fbase + (size_t)min(first + j * WAVE, N - 1)) * stride;
+            x[j] = *reinterpret_cast<const float*>(p);
+            y[j] = *reinterpret_cast<const float*>(p + 4);
+            z[j] = *reinterpret_cast<const float*>(p + 8);
+            rgb[j] = rgb_off >= 0 ? *reinterpret_cast<const uint32_t*>(p + rgb_off) : 0u;
+        }
     }
 }
 
@@ -47,13 +58,15 @@ __global__ void __launch_bounds__(BLOCK) k_crop_count(const char* __restrict__ i
     int cnt = 0;
     float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
     float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    float qx[ITEMS], qy[ITEMS], qz[ITEMS];
+    uint32_t qc[ITEMS];
+    load_rows<ITEMS>(in, stride, fbase, base + lane, N, rgb_off, qx, qy, qz, qc);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE + lane;
         bool keep = false;
         if (e < N) {
-            float x, y, z; uint32_t c;
-            load_point(in, stride, fbase + e, rgb_off, x, y, z, c);
+            const float x = qx[j], y = qy[j], z = qz[j];
             keep = crop_keep(x, y, z, lim);
             if (keep) {
                 mn[0] = fminf(mn[0], x); mn[1] = fminf(mn[1], y); mn[2] = fminf(mn[2], z);
@@ -183,15 +196,11 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
     uint32_t pc[ITEMS];
     uint64_t bal[ITEMS];
     int wtot = 0;
+    load_rows<ITEMS>(in, stride, fbase, base + lane, N, rgb_off, px, py, pz, pc);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE + lane;
-        bool keep = false;
-        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0;
-        if (e < N) {
-            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
-            keep = crop_keep(px[j], py[j], pz[j], lim);
-        }
+        const bool keep = e < N && crop_keep(px[j], py[j], pz[j], lim);
         bal[j] = __ballot(keep);
         wtot += __popcll(bal[j]);
     }
@@ -242,13 +251,12 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
     int wtot = 0;
     float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
     float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    load_rows<ITEMS>(in, stride, fbase, base + lane, N, rgb_off, px, py, pz, pc);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE + lane;
         bool keep = false;
-        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0;
         if (e < N) {
-            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
             keep = crop_keep(px[j], py[j], pz[j], lim);
             if (keep) {
                 mn[0] = fminf(mn[0], px[j]); mn[1] = fminf(mn[1], py[j]); mn[2] = fminf(mn[2], pz[j]);
@@ -327,6 +335,12 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
 // block - the host biases the field so that they do not).
 // Dropped: 4 bytes written per kept point, k_voxel_runs (a read of those keys, 0.12 ms), the key conversion in the first
 // scatter.  The chained scan carries both running counts (points, runs) in one 64-bit word.
+// What bounds it (round 4, profiles/r04_crop_variants.txt): a tile lives ~14 us - ticket, loads, scan and stores are round
+// trips in series - so the kernel moves bytes in proportion to the TILES IN FLIGHT per CU, i.e. to resident waves x rows per
+// wave.  443 us with 86 registers (5 waves per SIMD) and one load per round trip; 400 with the keys parked in LDS between
+// the phases (80 registers, 6 waves); 342 with all eight loads of a wave issued together (load_rows) = 5.5 TB/s.  Fewer rows
+// per wave on more threads goes the other way (4 rows x 512 threads 427 us, 2 x 1024 966 us: half the tiles in flight each
+// time), 16 rows x 128 threads gains nothing (349), and the ticket costs 3 us.
 constexpr int RUN_SHIFT_C = 20;   // as k_sort.hip's RUN_SHIFT: start < 2^20, length <= 64
 __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in, size_t stride, int N, int pitch,
                                                      int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
@@ -336,6 +350,8 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
     __shared__ int s_cnt[WAVES_PER_BLOCK], s_rcnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
     __shared__ uint32_t s_h[4][RADIX];
+    __shared__ uint32_t s_rk[TILE];   // the tile's run keys in order (for the histograms)
+    __shared__ uint32_t s_key[TILE];  // every element's key between the two phases (eight registers less per lane: one more wave per SIMD)
     __shared__ int s_excl, s_rexcl, s_ticket;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int F = gridDim.x / Tin;
@@ -347,19 +363,19 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
     const float inv = __fdiv_rn(1.0f, leaf);
     const float jlo = (float)kp.jlo, jhi = (float)(kp.jlo + ((1 << kp.bj) - 1));
     float px[ITEMS], py[ITEMS], pz[ITEMS];
-    uint32_t pc[ITEMS], key[ITEMS];
+    uint32_t pc[ITEMS];
     uint64_t bal[ITEMS], heads[ITEMS];
     int wtot = 0, rtot = 0;
     float mn[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f};
     float mx[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
     bool over = false;
+    load_rows<ITEMS>(in, stride, fbase, base + lane, N, rgb_off, px, py, pz, pc);
 #pragma unroll
     for (int j = 0; j < ITEMS; ++j) {
         const int e = base + j * WAVE + lane;
         bool keep = false;
-        px[j] = py[j] = pz[j] = 0.f; pc[j] = 0; key[j] = 0xffffffffu;
+        uint32_t key = 0xffffffffu;
         if (e < N) {
-            load_point(in, stride, fbase + e, rgb_off, px[j], py[j], pz[j], pc[j]);
             keep = crop_keep(px[j], py[j], pz[j], lim);
             if (keep) {
                 mn[0] = fminf(mn[0], px[j]); mn[1] = fminf(mn[1], py[j]); mn[2] = fminf(mn[2], pz[j]);
@@ -370,14 +386,15 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
                 const uint32_t ui = (uint32_t)((int)floorf(__fmul_rn(px[j], inv)) - kp.ilo);
                 const uint32_t uj = fits ? (uint32_t)((int)fy - kp.jlo) : 0u;
                 const uint32_t uk = (uint32_t)((int)floorf(__fmul_rn(pz[j], inv)) - kp.klo);
-                key[j] = ui | (uj << kp.bi) | (uk << (kp.bi + kp.bj));
+                key = ui | (uj << kp.bi) | (uk << (kp.bi + kp.bj));
             }
         }
         bal[j] = __ballot(keep);
         // a run starts at a kept point whose left neighbour in the row is not kept or lies in another cell
-        const uint32_t prev = (uint32_t)__shfl_up((int)key[j], 1, 64);
+        const uint32_t prev = (uint32_t)__shfl_up((int)key, 1, 64);
         const bool prev_kept = lane > 0 && ((bal[j] >> (lane - 1)) & 1ull);
-        heads[j] = __ballot(keep && !(prev_kept && prev == key[j]));
+        heads[j] = __ballot(keep && !(prev_kept && prev == key));
+        s_key[w * WAVE_SPAN + j * WAVE + lane] = key;   // (read back by this same lane only)
         wtot += __popcll(bal[j]);
         rtot += __popcll(heads[j]);
     }
@@ -411,7 +428,8 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
         }
     }
     __syncthreads();
-    int pos = s_excl, rpos = s_rexcl;
+    const int rexcl0 = s_rexcl;
+    int pos = s_excl, rpos = rexcl0;
     for (int k = 0; k < w; ++k) { pos += s_cnt[k]; rpos += s_rcnt[k]; }
     const uint64_t lt = lanemask_lt();
 #pragma unroll
@@ -425,37 +443,41 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
             const uint64_t stop = (~bal[j] | heads[j]) & (lane == 63 ? 0ull : ~((2ull << lane) - 1ull));
             const int next = stop ? __ffsll((long long)stop) - 1 : 64;
             const int ro = rpos + __popcll(heads[j] & lt);
+            const uint32_t key = s_key[w * WAVE_SPAN + j * WAVE + lane];
+            s_rk[ro - rexcl0] = key;
             if (ro < pitch) {
-                rkeys[obase + ro] = key[j];
+                rkeys[obase + ro] = key;
                 rvals[obase + ro] = (uint32_t)r | ((uint32_t)(next - lane) << RUN_SHIFT_C);
-            }
-        }
-        // digit histograms of the run keys.  The heads of a row (64 neighbouring pixels) nearly always share everything above the
-        // lowest digit - the y and z cells and the high bit of x: ONE test per row decides that, and then one lane adds the
-        // row's head count to the three upper bins (adds to one LDS word would serialise; and a test per digit, as k_voxel_runs
-        // has it, is ~60 scalar instructions per row on a kernel that was HBM-bound before it carried them)
-        if (heads[j]) {
-            const int first = __ffsll((long long)heads[j]) - 1;
-            const uint32_t up = key[j] >> RADIX_BITS;
-            const uint32_t up0 = (uint32_t)__builtin_amdgcn_readlane((int)up, first);
-            if (is_head) atomicAdd(&s_h[0][key[j] & (RADIX - 1)], 1u);
-            if (__ballot(is_head && up != up0) == 0ull) {
-                if (lane == first) {
-                    const uint32_t c = (uint32_t)__popcll(heads[j]);
-                    atomicAdd(&s_h[1][up0 & (RADIX - 1)], c);
-                    atomicAdd(&s_h[2][(up0 >> RADIX_BITS) & (RADIX - 1)], c);
-                    atomicAdd(&s_h[3][up0 >> (2 * RADIX_BITS)], c);
-                }
-            } else if (is_head) {
-                atomicAdd(&s_h[1][up & (RADIX - 1)], 1u);
-                atomicAdd(&s_h[2][(up >> RADIX_BITS) & (RADIX - 1)], 1u);
-                atomicAdd(&s_h[3][up >> (2 * RADIX_BITS)], 1u);
             }
         }
         pos += __popcll(bal[j]);
         rpos += __popcll(heads[j]);
     }
     if (__ballot(over) != 0ull && lane == 0) fs[f].crop_overflow = 1;
+    __syncthreads();
+    // digit histograms of the tile's run keys, 64 runs per wave trip over the tile's compacted run keys (a row of 64 pixels
+    // holds ~10 runs: per row it is 32 trips per wave instead of ~6; the whole histogram costs 18 of the kernel's 342 us).
+    // Lowest digit: one add per run (x changes from run to run).  Upper digits: neighbouring runs mostly share them, and adds
+    // to one LDS word would serialise - the first lane of each stretch of equal digits adds its length.
+    {
+        int nr = 0;
+        for (int k = 0; k < WAVES_PER_BLOCK; ++k) nr += s_rcnt[k];
+        for (int q0 = w * WAVE; q0 < nr; q0 += BLOCK) {
+            const int q = q0 + lane;
+            const bool on = q < nr;
+            const uint32_t kq = on ? s_rk[q] : 0u;
+            if (on) atomicAdd(&s_h[0][kq & (RADIX - 1)], 1u);
+#pragma unroll
+            for (int d = 1; d < 4; ++d) {
+                const uint32_t dg = on ? ((kq >> (d * RADIX_BITS)) & (RADIX - 1)) : 0xffffffffu;   // past the end: own stretch
+                const uint32_t prev = (uint32_t)__shfl_up((int)dg, 1, 64);
+                const uint64_t hd = __ballot(lane == 0 || dg != prev);
+                const uint64_t above = lane == 63 ? 0ull : hd & ~((2ull << lane) - 1ull);
+                const int next = above ? __ffsll((long long)above) - 1 : 64;
+                if (((hd >> lane) & 1ull) && on) atomicAdd(&s_h[d][dg], (uint32_t)(next - lane));
+            }
+        }
+    }
     __syncthreads();
     for (int q = threadIdx.x; q < 4 * RADIX; q += BLOCK) {
         const uint32_t c = (&s_h[0][0])[q];
@@ -464,8 +486,24 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
 }
 
 // ---- voxel run heads in the sorted key array -------------------------------------------
-__device__ __forceinline__ bool is_head(const uint32_t* __restrict__ k, int e, int n) {
-    return e < n && (e == 0 || k[e] != k[e - 1]);
+// heads[j] = ballot of "element first + j * 64 + lane starts a voxel" (its key differs from its left neighbour's).  All keys
+// of the wave's rows are loaded first (clamped indices, no branch around a load: see load_rows); a lane's left neighbour is the
+// lane below it, lane 0 takes the element before the row from memory.
+template <int R>
+__device__ __forceinline__ void head_ballots(const uint32_t* __restrict__ k, int first, int n, uint64_t (&heads)[R]) {
+    const int lane = threadIdx.x & 63;
+    uint32_t cur[R], left[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int e = first + j * WAVE + lane;
+        cur[j] = k[max(min(e, n - 1), 0)];
+        left[j] = k[max(min(e - 1, n - 1), 0)];   // (the same cache lines as cur: no second trip to memory)
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const int e = first + j * WAVE + lane;
+        heads[j] = __ballot(e < n && (e == 0 || cur[j] != left[j]));
+    }
 }
 
 // One QUAD per voxel.  The 4 lanes fetch 4 consecutive members of the voxel's run at once (indices,
@@ -502,11 +540,9 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;
+    head_ballots<ITEMS>(k, base, n, bal);
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
-        wtot += __popcll(bal[j]);
-    }
+    for (int j = 0; j < ITEMS; ++j) wtot += __popcll(bal[j]);
     if (lane == 0) s_cnt[w] = wtot;
     __syncthreads();
     int pos = 0, nheads = 0;
@@ -587,11 +623,9 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;
+    head_ballots<ITEMS>(k, base, n, bal);
 #pragma unroll
-    for (int j = 0; j < ITEMS; ++j) {
-        bal[j] = __ballot(is_head(k, base + j * WAVE + lane, n));
-        wtot += __popcll(bal[j]);
-    }
+    for (int j = 0; j < ITEMS; ++j) wtot += __popcll(bal[j]);
     if (lane == 0) s_cnt[w] = wtot;
     __syncthreads();
     int pos = 0, nheads = 0;
@@ -610,57 +644,108 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
     __syncthreads();
     const int out0 = s_out0;
     const int quad = threadIdx.x >> 2, ql = threadIdx.x & 3;
-    for (int h = quad; h < nheads; h += BLOCK / 4) {
-        const int e0 = s_head[h];
-        const uint32_t key = k[e0];
-        float sx = 0.f, sy = 0.f, sz = 0.f, cr = 0.f, cg = 0.f, cb = 0.f;
+    // Latency plan (round 4): a wave spent ~10 dependent memory round trips per group of 16 voxels - the voxel's key, its run
+    // records, the first four points of four runs, then one more trip for EVERY run index that is longer than four points in
+    // some quad (13 % of the runs are), and all of it again for the 20 % of voxels with more than four runs.  Now the first
+    // four records of a voxel are fetched one voxel AHEAD and carry the key (record e0 is the voxel's first run), the next
+    // four records are fetched while the current four are summed, and points 4..7 of every run go out together with points
+    // 0..3: ~2.6 round trips per group (one per four runs), the rest is the summation itself.
+    // Colour: exact integer channel sums (v_dot4_u32_u8: one instruction per channel) converted once - equal to PCL's float
+    // sums as long as every partial sum is below 2^24, i.e. for voxels of at most 65 536 points; a larger voxel (a fifth of a
+    // 640 x 480 frame in one 5 mm cell) is re-summed in float by the loop at the end.
+    int h = quad, e0 = 0;
+    uint32_t kk = 0, rec = 0;
+    bool have = false;
+    if (h < nheads) {
+        e0 = s_head[h];
+        have = e0 + ql < n;
+        if (have) { kk = k[e0 + ql]; rec = v[e0 + ql]; }
+    }
+    while (h < nheads) {
+        const int hn = h + BLOCK / 4;
+        int ne0 = 0;
+        uint32_t nkk = 0, nrec = 0;
+        bool nhave = false;
+        if (hn < nheads) {
+            ne0 = s_head[hn];
+            nhave = ne0 + ql < n;
+            if (nhave) { nkk = k[ne0 + ql]; nrec = v[ne0 + ql]; }
+        }
+        const uint32_t key = (uint32_t)quad_bcast_i<0>((int)kk);
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        uint32_t ir = 0, ig = 0, ib = 0;
         int cnt = 0;
-        // Four run records per trip (lane ql of the quad fetches record eb + ql), then the first four points of each of the
-        // four runs - sixteen independent loads in flight per quad before the first addition; runs of a voxel are contiguous
-        // in the sorted order, so the members are a prefix of the four.  The additions replay the input order: run by run,
-        // point by point.
 #define CD_ADD(P, J)                                                                                   \
         {                                                                                              \
             sx = __fadd_rn(sx, quad_bcast<J>(P.x)); sy = __fadd_rn(sy, quad_bcast<J>(P.y));            \
             sz = __fadd_rn(sz, quad_bcast<J>(P.z));                                                    \
             if (rgb_on) {                                                                              \
                 const uint32_t u = __float_as_uint(quad_bcast<J>(P.w));                                \
-                cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff); \
+                ir = __builtin_amdgcn_udot4(u, 0x00010000u, ir, false);                                \
+                ig = __builtin_amdgcn_udot4(u, 0x00000100u, ig, false);                                \
+                ib = __builtin_amdgcn_udot4(u, 0x00000001u, ib, false);                                \
             }                                                                                          \
             ++cnt;                                                                                     \
         }
-#define CD_RUN(I, P)                                                                                   \
+#define CD_RUN(I, P, Q)                                                                                \
         if (len##I > 0) {                                                                              \
             CD_ADD(P, 0)                                                                               \
             if (len##I > 1) CD_ADD(P, 1)                                                               \
             if (len##I > 2) CD_ADD(P, 2)                                                               \
             if (len##I > 3) CD_ADD(P, 3)                                                               \
-            for (int i = 4; i < len##I; i += 4) {       /* longer runs: the rest, four points per trip */ \
-                float4 q = make_float4(0.f, 0.f, 0.f, 0.f);                                            \
-                if (i + ql < len##I) q = cpt[fbase + start##I + i + ql];                               \
-                CD_ADD(q, 0)                                                                           \
-                if (len##I - i > 1) CD_ADD(q, 1)                                                       \
-                if (len##I - i > 2) CD_ADD(q, 2)                                                       \
-                if (len##I - i > 3) CD_ADD(q, 3)                                                       \
+            if (len##I > 4) {                                                                          \
+                CD_ADD(Q, 0)                                                                           \
+                if (len##I > 5) CD_ADD(Q, 1)                                                           \
+                if (len##I > 6) CD_ADD(Q, 2)                                                           \
+                if (len##I > 7) CD_ADD(Q, 3)                                                           \
+                for (int i = 8; i < len##I; i += 4) {   /* longer runs: the rest, four points per trip */ \
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
+                    if (i + ql < len##I) t = cpt[fbase + start##I + i + ql];                           \
+                    CD_ADD(t, 0)                                                                       \
+                    if (len##I - i > 1) CD_ADD(t, 1)                                                   \
+                    if (len##I - i > 2) CD_ADD(t, 2)                                                   \
+                    if (len##I - i > 3) CD_ADD(t, 3)                                                   \
+                }                                                                                      \
             }                                                                                          \
         }
         for (int eb = e0;; eb += 4) {
-            const int me = eb + ql;
-            uint32_t kk = ~key, rec = 0;
-            if (me < n) { kk = k[me]; rec = v[me]; }
-            const int mylen = kk == key ? (int)(rec >> 20) : 0, mystart = (int)(rec & ((1u << 20) - 1u));
+            // lane ql of the quad holds record eb + ql (kk, rec, have)
+            const int mylen = (have && kk == key) ? (int)(rec >> 20) : 0, mystart = (int)(rec & ((1u << 20) - 1u));
             const int len0 = quad_bcast_i<0>(mylen), len1 = quad_bcast_i<1>(mylen), len2 = quad_bcast_i<2>(mylen), len3 = quad_bcast_i<3>(mylen);
             const int start0 = quad_bcast_i<0>(mystart), start1 = quad_bcast_i<1>(mystart), start2 = quad_bcast_i<2>(mystart), start3 = quad_bcast_i<3>(mystart);
-            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
+            // the next four records, in case the voxel goes on (runs of a voxel are contiguous in the sorted order, so its
+            // members are a prefix of every group of four)
+            uint32_t kk2 = 0, rec2 = 0;
+            const bool have2 = len3 > 0 && eb + 4 + ql < n;
+            if (have2) { kk2 = k[eb + 4 + ql]; rec2 = v[eb + 4 + ql]; }
+            float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
             if (ql < len0) p0 = cpt[fbase + start0 + ql];
             if (ql < len1) p1 = cpt[fbase + start1 + ql];
             if (ql < len2) p2 = cpt[fbase + start2 + ql];
             if (ql < len3) p3 = cpt[fbase + start3 + ql];
-            CD_RUN(0, p0) CD_RUN(1, p1) CD_RUN(2, p2) CD_RUN(3, p3)
+            if (4 + ql < len0) q0 = cpt[fbase + start0 + 4 + ql];
+            if (4 + ql < len1) q1 = cpt[fbase + start1 + 4 + ql];
+            if (4 + ql < len2) q2 = cpt[fbase + start2 + 4 + ql];
+            if (4 + ql < len3) q3 = cpt[fbase + start3 + 4 + ql];
+            // the additions replay the input order: run by run, point by point
+            CD_RUN(0, p0, q0) CD_RUN(1, p1, q1) CD_RUN(2, p2, q2) CD_RUN(3, p3, q3)
             if (len3 == 0) break;    // the voxel's runs ended inside this group of four
+            kk = kk2; rec = rec2; have = have2;
         }
 #undef CD_RUN
 #undef CD_ADD
+        float cr = (float)ir, cg = (float)ig, cb = (float)ib;
+        if (rgb_on && cnt > 65536) {   // partial sums beyond 2^24 round in PCL's float accumulation: replay it
+            cr = cg = cb = 0.f;
+            for (int e = e0; e < n && k[e] == key; ++e) {
+                const uint32_t r = v[e];
+                const int st = (int)(r & ((1u << 20) - 1u)), ln = (int)(r >> 20);
+                for (int i = 0; i < ln; ++i) {
+                    const uint32_t u = __float_as_uint(cpt[fbase + st + i].w);
+                    cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff);
+                }
+            }
+        }
         if (ql == 0) {
             const float c = (float)cnt;
             uint32_t packed = 0;
@@ -670,6 +755,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
             }
             vox[fbase + out0 + h] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
         }
+        h = hn; e0 = ne0; kk = nkk; rec = nrec; have = nhave;
     }
 }
 

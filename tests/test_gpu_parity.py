@@ -122,6 +122,48 @@ def test_voxel_random_ragged_cloud(ctx, O):
     assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
 
 
+def test_voxel_long_runs_and_a_voxel_of_70000_points(ctx, O):
+    """The centroid kernel's corners: runs longer than the eight points it fetches up front (64 neighbours in one voxel),
+    voxels of many runs (the same voxel visited again and again), and a voxel of more than 65 536 points, whose colour sums
+    pass 2^24 - there PCL's float accumulation rounds, and the kernel's integer channel sums are replayed in float."""
+    rng = np.random.RandomState(11)
+    n = 120000
+    rec = np.zeros((n, 4), np.float32)
+    # 70 000 points inside ONE 5 mm voxel (cell [0.100, 0.105) x [0.000, 0.005) x [0.500, 0.505)), bright colours
+    rec[:70000, :3] = rng.uniform([0.1002, 0.0002, 0.5002], [0.1048, 0.0048, 0.5048], (70000, 3))
+    # red channel: values whose exact mean sits a few 1/70000 beside an integer while PCL's sequential float sum (rounded to
+    # even above 2^24) lands on the other side of it - integer sums and float sums give different colours here
+    fsum = lambda v: float(np.cumsum(v.astype(np.float32), dtype=np.float32)[-1])
+    red = None
+    for _ in range(20):
+        cand = rng.randint(236, 256, 70000).astype(np.int64)
+        d = fsum(cand) - int(cand.sum())
+        if abs(d) < 8:
+            continue
+        delta = 70000 * int(round(cand.sum() / 70000)) - int(np.sign(d)) * int(abs(d) // 2) - int(cand.sum())
+        step = 1 if delta > 0 else -1
+        cand[np.nonzero((cand + step >= 1) & (cand + step <= 254))[0][:abs(delta)]] += step
+        if int(np.float32(cand.sum()) / np.float32(70000)) != int(np.float32(fsum(cand)) / np.float32(70000)):
+            red = cand
+            break
+    assert red is not None
+    rec[:70000, 3] = ((red.astype(np.uint32) << 16) | rng.randint(0, 1 << 16, 70000).astype(np.uint32)).view(np.float32)
+    # stretches of 64 / 20 / 9 neighbours per voxel, the voxels revisited in a scrambled order (many runs per voxel)
+    cells = rng.randint(0, 40, 50000 // 10)
+    pts = np.repeat(cells, 10)[:50000]
+    rec[70000:, 0] = -0.15 + 0.005 * (pts % 8) + rng.uniform(0.0005, 0.0045, 50000)
+    rec[70000:, 1] = 0.005 * (pts // 8) + rng.uniform(0.0005, 0.0045, 50000)
+    rec[70000:, 2] = 0.7 + rng.uniform(0.0005, 0.0045, 50000)
+    rec[70000:, 3] = rng.randint(0, 1 << 24, 50000).astype(np.uint32).view(np.float32)
+    rec[70000:70200, :3] = rec[70000, :3]                 # one run of 64 + 64 + 64 + 8 identical neighbours
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+    vox, rgb, nc = ctx.crop_voxel(rec, prm, want_rgb=True)
+    st, vo, ro, nco, _ = O.crop_voxel(rec, prm, want_rgb=True)
+    assert st == 0 and nc == nco == n and vox.shape == vo.shape
+    assert np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+
+
 def test_segment_plane_bit_exact(ctx, O, frames4):
     prm = capi.default_params()
     for f in frames4[:2]:

@@ -6,7 +6,7 @@ n=0
 for pass in "$@"; do
   n=$((n+1))
   rm -rf /tmp/pmc_$n
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_$n -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-verify > /tmp/pmc_$n.log 2>&1 || { tail -5 /tmp/pmc_$n.log; exit 1; }
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/pmc_$n -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-latency --no-verify --no-legs > /tmp/pmc_$n.log 2>&1 || { tail -5 /tmp/pmc_$n.log; exit 1; }
   echo "== pass $n: $pass"
   python3 $R/tools/pmc_summary.py /tmp/pmc_$n > /tmp/pmc_$n.txt; grep -E "${KERNELS:-k_icp}" /tmp/pmc_$n.txt
 done
