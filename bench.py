@@ -634,7 +634,7 @@ def main():
         regime = None
         if serial_t is not None and serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0:
             excl_ms = float(serial_t.icp_kernel_ms)
-            regime = {"slots": serial_t.icp_regime >> 16, "workgroups": serial_t.icp_regime & 0xffff}
+            regime = {"slots": serial_t.icp_regime >> 16, "workgroups": serial_t.icp_regime & 0xffff, "handovers": int(getattr(serial_t, "icp_handovers", 0))}
         head_ms = excl_ms if excl_ms is not None else avg_launch_ms
         head_achieved = per_launch_bytes / (head_ms * 1e-3) / 1e9
         timed_regime = None

@@ -315,6 +315,10 @@ typedef struct cd_timing {
                                                    * workgroup << 16) | workgroups; 0 = no such launch (sliced driver).  The shape is
                                                    * chosen from the calls in flight on the device (scheduling only: results do not
                                                    * depend on it), so a measurement can say which shape it measured                    */
+    int32_t icp_handovers;                        /* running clusters that changed workgroup inside that launch (a call that has the GPU to
+                                                   * itself lets workgroups without work take over clusters from those that still have
+                                                   * several: scheduling only, results do not depend on it)                             */
+    int32_t reserved;
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

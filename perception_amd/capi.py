@@ -94,6 +94,7 @@ class CdTiming(C.Structure):
         ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32), ("icp_persist_gave_up", C.c_int32),
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
         ("scan_retries", C.c_int32), ("icp_regime", C.c_int32),
+        ("icp_handovers", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

@@ -65,6 +65,8 @@ struct cd_context {
     int* d_nn = nullptr;                                          // last NN index of every ICP source point
     float* d_d2 = nullptr;                                        // its squared distance
     int* d_queue = nullptr;                                       // ICP work queue heads (one per template group)
+    int* d_don = nullptr;                                         // k_icp_pipe: hand-over control block + mailbox (common.hpp DON_*)
+    int icp_donate = -1;                                          // CUBOID_ICP_DONATE: -1 auto (a call alone on the device), 0 never, 1 always
     int* d_wgtab = nullptr;                                       // k_icp_pipe: {first item, end item, queue} per workgroup
     int* h_wgtab = nullptr;                                       // its pinned staging copy (3 * 1024 ints)
     int* h_ctl = nullptr;                                         // pinned: control words of k_icp_persist going up [0..7], coming back [8]
@@ -663,7 +665,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // four 4 x 128 wins 52.9 : 49.7 k - and the last launches of a burst, which soon have the GPU to themselves, spread out)
     const bool crowded = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 4;
     ip.pipe_slots = c->icp_slots > 0 ? std::min(c->icp_slots, CD_PIPE_SLOTS) : (crowded ? CD_PIPE_SLOTS : std::min(2, CD_PIPE_SLOTS));
-    ip.pad_ = 0;
+    ip.donate = 0;   // (set below for a whole-cluster launch that has the GPU to itself)
+    ip.don = c->d_don;
     auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
         if (c->icp_cpw > 0) return std::min((n_items + c->icp_cpw - 1) / c->icp_cpw, cap);
         if (!crowded || n_items <= cap) return std::min(n_items, cap);
@@ -783,7 +786,16 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
             HIPCHK(c, hipStreamWaitEvent(si, c->ev2[0], 0));
         }
-        if (pipe_ok || big_ok) c->timing.icp_regime = (ip.pipe_slots << 16) | pipe_grid(ncl, wg_cap);
+        if (pipe_ok || big_ok) {
+            c->timing.icp_regime = (ip.pipe_slots << 16) | pipe_grid(ncl, wg_cap);
+            // A launch that has the GPU to itself lets workgroups that run out of clusters wait and take over running ones
+            // (k_icp.hip, "hand-over of running clusters"): the launch is as long as its slowest workgroup, and the bench batch's
+            // slowest runs 25 % over the average.  With other calls in flight a waiting workgroup would sit on a CU their
+            // kernels could use, and what counts there is the CU-time a batch costs, which hand-overs do not lower.
+            const bool alone = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() <= 1;
+            ip.donate = (c->icp_donate < 0 ? (alone && ncl > pipe_grid(ncl, wg_cap)) : c->icp_donate != 0) ? 1 : 0;
+            if (ip.donate) HIPCHK(c, hipMemsetAsync(c->d_don, 0, sizeof(int) * (size_t)(DON_BOX + DON_CAP), c->stream));
+        }
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
                             c->d_queue, pipe_grid(ncl, wg_cap), nullptr, ip));
@@ -801,10 +813,17 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         c->timing.icp_kernel_launches = 1;
         HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        if (ip.donate) HIPCHK(c, hipMemcpyAsync(c->h_ctl + 12, c->d_don, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms1 = 0.f;
         hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
         c->timing.icp_kernel_ms = ms1;
+        if (ip.donate) {
+            const int* w = c->h_ctl + 12;   // (copied with the records above)
+            c->timing.icp_handovers = w[DON_HEAD];
+            if (std::getenv("CUBOID_DEBUG"))
+                std::fprintf(stderr, "cuboid_hip: hand-overs: %d published, %d taken, %d clusters finished of %d, waiting balance %d\n", w[DON_TAIL], w[DON_HEAD], w[DON_FINISHED], ncl, w[DON_AVAIL]);
+        }
         if (pair_tests) {
             long long tot = 0;
             for (int k = 0; k < ncl; ++k)
@@ -1274,7 +1293,7 @@ void cd_destroy(cd_context* c) {
     void* dev[] = {c->d_in, c->d_fs, c->d_tileA, c->d_tileB, c->d_tileK, c->d_cpt, c->d_vox, c->d_obj, c->d_src0, c->d_src,
                    c->d_key[0], c->d_key[1], c->d_val[0], c->d_val[1], c->d_ghist, c->d_sstate, c->d_ticket, c->d_tile64, c->d_rnd, c->d_models, c->d_valid, c->d_counts,
                    c->d_active, c->d_model, c->d_have, c->d_sums, c->d_plane_idx, c->d_head, c->d_next, c->d_parent, c->d_csize,
-                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
+                   c->d_rank, c->d_cand, c->d_sizes, c->d_label, c->d_tpl, c->d_tlo, c->d_thi, c->d_tplk, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_nn, c->d_d2, c->d_queue, c->d_don, c->d_wgtab, c->d_order, c->d_cl, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     if (c->d_koffx) hipFree(c->d_koffx);
     if (c->d_guess) hipFree(c->d_guess);
@@ -1340,7 +1359,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_tlo, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thi, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
     ok = ok && dalloc(&c->d_kdmap, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_tplk, (size_t)c->tpl_cap) == hipSuccess && dalloc(&c->d_tlok, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess && dalloc(&c->d_thik, (size_t)c->tpl_cap / ICP_SUB) == hipSuccess;
-    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)16) == hipSuccess && dalloc(&c->d_wgtab, (size_t)3 * 1024) == hipSuccess;
+    ok = ok && dalloc(&c->d_nn, FN) == hipSuccess && dalloc(&c->d_d2, FN) == hipSuccess && dalloc(&c->d_queue, (size_t)16) == hipSuccess && dalloc(&c->d_don, (size_t)(DON_BOX + DON_CAP)) == hipSuccess && dalloc(&c->d_wgtab, (size_t)3 * 1024) == hipSuccess;
     ok = ok && halloc(&c->h_wgtab, (size_t)3 * 1024) == hipSuccess && halloc(&c->h_ctl, (size_t)16) == hipSuccess;
     {
         hipDeviceProp_t prop;
@@ -1354,6 +1373,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_MAX_WG")) c->icp_max_wg = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_DONATE")) c->icp_donate = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;

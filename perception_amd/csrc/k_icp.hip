@@ -210,6 +210,20 @@ extern "C" int cd_debug_icp_stats(unsigned long long* out, int reset) {
 }
 #endif
 
+#ifdef CD_DONDBG
+// hand-over timeline (tools/probe_handover.py): [1] latest workgroup end, [2] ticks spent waiting, [8 + b] waits begun,
+// [24 + b] clusters published, [40 + b] clusters taken in quarter-millisecond bin b of the workgroup's own life (100 MHz ticks)
+__device__ unsigned long long g_don_dbg[64];
+extern "C" int cd_debug_don(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_don_dbg), sizeof(g_don_dbg)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_don_dbg), z, sizeof(z)); }
+    return 0;
+}
+#define DON_DBG(slot0, t0) atomicAdd(&g_don_dbg[(slot0) + min(15, (int)((wall_clock64() - (t0)) / 25000))], 1ull)
+#else
+#define DON_DBG(slot0, t0)
+#endif
+
 #ifdef CD_STATS
 // far queries (seed ball wider than the grid walk's reach) by iteration class (0: it < 3, 1: it < 16, 2: later) and by the
 // radius of the seed ball in grid cells (bucket 15: 15 or more)
@@ -1520,6 +1534,7 @@ struct PipeSlot {
     int arrived;                    // waves that finished their share of the current step
     int epoch;                      // steps completed (solved) so far
     int next_pass;                  // next 64-point pass of the current step nobody has taken yet
+    int give;                       // 1: the cluster is promised to a waiting workgroup - this step's stores are fenced at agent scope, then it goes
 };
 
 // Umeyama + convergence test of one iteration (lane 0 of the finishing wave); same code as k_icp_solve.
@@ -1554,18 +1569,84 @@ __device__ __noinline__ int pipe_solve(PipeSlot* sl, const IcpParams& prm) {
 
 // next cluster from the global queue into the slot (lane 0 of the finishing wave)
 // (items [gbeg, gend) of `order`: the clusters that share the workgroup's template)
-__device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, const int* order, const IcpCluster* cl, const IcpState* st, int* queue) {
+__device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, const int* order, const IcpCluster* cl, const IcpState* st, int* queue,
+                                            int* don) {
+    sl->give = 0;
     for (;;) {
         const int item = gbeg + atomicAdd(queue, 1);
         if (item >= gend) { sl->phase = PH_EXHAUSTED; return; }
         const int k = order[item];
-        if (st[2 * (size_t)k].done) continue;            // host pre-marked (too few points / no template)
+        if (st[2 * (size_t)k].done) {                    // host pre-marked (too few points / no template)
+            if (don) __hip_atomic_fetch_add(don + DON_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            continue;
+        }
         const IcpCluster c = cl[k];
         sl->src_off = c.src_off; sl->n = c.n; sl->k = k;
         sl->so = st[2 * (size_t)k];
         sl->phase = PH_ITER; sl->it = 0;
         return;
     }
+}
+
+// ---- hand-over of running clusters (IcpParams::donate; launches that have the GPU to themselves) ---------------------------
+// The bench batch is 522 clusters on 256 workgroups: two each, of 6 to 100 iterations that nothing predicts - the slowest
+// workgroup runs 4.4 ms, the average one 3.5 (tools/probe_balance.py).  A workgroup that finds the queue empty with nothing
+// left of its own therefore WAITS (one lane polls, the others sit at a barrier) instead of ending, and a workgroup that still
+// has two or more clusters going gives one of them away:
+//   waiter : DON_AVAIL += 1, then polls the mailbox (and DON_FINISHED == clusters of the launch -> ends)
+//   donor  : at a step boundary sees DON_AVAIL > 0, takes one (DON_AVAIL -= 1: one promise per waiter) and sets the slot's `give`;
+//            during the NEXT step every wave fences its stores of the cluster's points and neighbour indices at AGENT scope
+//            before it arrives (they must reach memory: the taker may sit on another XCD, whose L2 is not coherent with this
+//            one); at the end of that step the finishing wave writes the slot's IcpState to st[], fences, and publishes the
+//            cluster id in the next mailbox entry.  (A cluster that converged in that very step is not handed over: the
+//            promise is returned, DON_AVAIL += 1.)
+//   taker  : acquires the entry (agent-scope fence: its CU's L1 and its XCD's L2 drop what they hold), reloads the state,
+//            and carries on from iteration so.iters - the arithmetic does not depend on who executes it, so the records are
+//            bit-identical with or without hand-overs (tests/test_gpu_timed_path.py).
+// Nobody ever waits for a donor or a taker: donors never block, and a waiter's poll ends when every cluster is finished,
+// which the running workgroups reach on their own.  Both polls carry a bound all the same.
+__device__ __forceinline__ int don_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int pipe_active_slots(const PipeSlot* slots) {
+    int a = 0;
+    for (int i = 0; i < PIPE_SLOTS; ++i) a += (slots[i].phase == PH_ITER || slots[i].phase == PH_FIT) ? 1 : 0;
+    return a;
+}
+// lane 0 of the finishing wave, cluster not converged: returns true when the slot's cluster went to the mailbox
+__device__ __noinline__ bool pipe_give(PipeSlot* sl, const PipeSlot* slots, IcpState* st, int* don) {
+    bool gone = false;
+    if (pipe_active_slots(slots) >= 2) {
+        st[2 * (size_t)sl->k] = sl->so;
+        st[2 * (size_t)sl->k + 1] = sl->so;
+        __threadfence();
+        const int t = __hip_atomic_fetch_add(don + DON_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t < DON_CAP) {
+            __hip_atomic_store(don + DON_BOX + t, sl->k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            gone = true;
+        }
+    }
+    if (!gone) __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // promise returned
+    sl->give = 0;
+    return gone;
+}
+// thread 0 of a workgroup with nothing left: the id of a cluster to carry on with, or -1 when the launch is finished
+__device__ __noinline__ int pipe_wait_for_cluster(int* don, int total) {
+    __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int polls = 0; polls < (1 << 22); ++polls) {
+        const int head = don_load(don + DON_HEAD), tail = min(don_load(don + DON_TAIL), DON_CAP);
+        if (head < tail) {
+            int expect = head;
+            if (__hip_atomic_compare_exchange_strong(don + DON_HEAD, &expect, head + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                int v = 0;
+                for (int spins = 0; spins < (1 << 24) && v == 0; ++spins) v = __hip_atomic_load(don + DON_BOX + head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence();
+                return v - 1;   // (-1 only if the entry never appeared: its writer increments DON_TAIL and stores the entry back to back)
+            }
+            continue;
+        }
+        if (don_load(don + DON_FINISHED) >= total) return -1;
+        __builtin_amdgcn_s_sleep(32);
+    }
+    return -1;
 }
 
 // BIG = false: k_icp_pipe, the template (<= ICP_TPL_LDS points) and its k-d position table live in LDS.
@@ -1599,6 +1680,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     // workgroup b; without a table all clusters share one template and one queue.
     int gbeg = 0, gend = ncl;
     if (wgtab) { gbeg = wgtab[3 * blockIdx.x]; gend = wgtab[3 * blockIdx.x + 1]; queue += wgtab[3 * blockIdx.x + 2]; }
+    int* const don = (prm.donate && !wgtab) ? prm.don : nullptr;   // (hand-overs: launches with one queue only)
+    __shared__ int s_take;
     const IcpCluster c0 = cl[order[gbeg]];
     const IcpGrid g = grids[c0.slot];
     const float4* tp = tpl + c0.tpl_off;
@@ -1655,21 +1738,25 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             PipeSlot* sl = &s_slot[sidx];
             for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
-            sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0;
+            sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0; sl->give = 0;
             sl->phase = sidx < prm.pipe_slots ? PH_FILL : PH_EXHAUSTED;   // (a slot the launch does not use is dropped at its first visit)
         }
         // slot 0 starts with a cluster; the other slots are filled at their first step (PH_FILL), after every workgroup took its first
-        pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue);
+        pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue, don);
     }
     __syncthreads();
 #ifdef CD_TIMERS
     long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
     const long long wg_t0 = wall_clock64();
 #endif
+#ifdef CD_DONDBG
+    const long long don_t0 = wall_clock64();
+#endif
     // per wave: the steps it has completed on each slot (one byte per slot, mod 256: waves are never a whole step apart) and
     // the slots that still have work
     unsigned long long my_ep = 0ull;
     unsigned live = (1u << PIPE_SLOTS) - 1u;
+    for (;;) {
     while (live) {
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             if (!((live >> sidx) & 1u)) continue;
@@ -1680,6 +1767,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             CD_PHASE(0)
             const int phase = sl->phase;
             if (phase == PH_EXHAUSTED) { live &= ~(1u << sidx); continue; }
+            const int give = sl->give;   // the cluster leaves this workgroup after this step: its stores must reach memory
             if (phase == PH_ITER || phase == PH_FIT) {
                 const int it = sl->it, n = sl->n;
                 float4* pts = src + sl->src_off;
@@ -1835,7 +1923,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                 }
                 CD_PHASE(5)
             }
-            __threadfence_block();
+            if (give) __threadfence(); else __threadfence_block();
             int a = 0;
             if (lane == 0) a = atomicAdd(&sl->arrived, 1);
             a = __builtin_amdgcn_readfirstlane(a);
@@ -1843,7 +1931,21 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                 __threadfence_block();
                 if (lane == 0) {
                     if (phase == PH_ITER) {
-                        if (pipe_solve(sl, prm)) sl->phase = PH_FIT; else sl->it += 1;
+                        // (the load is in flight while the step is solved)
+                        const int waiting = don ? don_load(don + DON_AVAIL) : 0;
+                        if (pipe_solve(sl, prm)) {
+                            sl->phase = PH_FIT;
+                            if (sl->give) { sl->give = 0; __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // converged: stays
+                        } else {
+                            sl->it += 1;
+                            if (sl->give) {
+                                if (pipe_give(sl, s_slot, st, don)) { DON_DBG(24, don_t0); pipe_refill(sl, gbeg, gend, order, cl, st, queue, don); }
+                            } else if (waiting > 0 && pipe_active_slots(s_slot) >= 2) {
+                                // promise this cluster to one of the waiting workgroups; it goes after the next step
+                                if (__hip_atomic_fetch_add(don + DON_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) sl->give = 1;
+                                else __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+                        }
                     } else {
                         if (phase == PH_FIT) {
                             sl->so.done = 1;
@@ -1851,8 +1953,9 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                             st[2 * (size_t)sl->k] = sl->so;
                             st[2 * (size_t)sl->k + 1] = sl->so;
                             accf[sl->k] = sl->acc[0];
+                            if (don) __hip_atomic_fetch_add(don + DON_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        pipe_refill(sl, gbeg, gend, order, cl, st, queue);
+                        pipe_refill(sl, gbeg, gend, order, cl, st, queue, don);
                     }
                     for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
                     sl->arrived = 0;
@@ -1864,6 +1967,35 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             }
             my_ep = (my_ep & ~(0xffull << (8 * sidx))) | ((unsigned long long)((want + 1) & 0xff) << (8 * sidx));
         }
+    }
+    // nothing left here.  With hand-overs on, wait for a running cluster of a workgroup that still has several (see pipe_give):
+    // it goes into slot 0, whose step counter every wave left at the slot's current epoch.
+    if (!don) break;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        DON_DBG(8, don_t0);
+#ifdef CD_DONDBG
+        const long long tw0 = wall_clock64();
+#endif
+        const int k = pipe_wait_for_cluster(don, gend - gbeg);
+#ifdef CD_DONDBG
+        atomicAdd(&g_don_dbg[2], (unsigned long long)(wall_clock64() - tw0));
+        if (k >= 0) DON_DBG(40, don_t0); else atomicMax(&g_don_dbg[1], (unsigned long long)(wall_clock64() - don_t0));
+#endif
+        s_take = k;
+        if (k >= 0) {
+            PipeSlot* sl = &s_slot[0];
+            const IcpCluster c = cl[k];
+            sl->src_off = c.src_off; sl->n = c.n; sl->k = k;
+            sl->so = st[2 * (size_t)k];
+            sl->phase = PH_ITER; sl->it = sl->so.iters; sl->give = 0;
+            for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
+            sl->arrived = 0; sl->next_pass = 0;
+        }
+    }
+    __syncthreads();
+    if (s_take < 0) break;
+    live = 1u;
     }
 #ifdef CD_TIMERS
     if (lane == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_icp_stats[8 + i], (unsigned long long)tph[i]);

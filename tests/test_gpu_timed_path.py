@@ -111,3 +111,38 @@ def test_pipe_slot_refill_with_capped_grid(O, template, max_wg, slots, monkeypat
         assert np.array_equal(capi.results_to_array(res), pipe_bytes)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("slots", ["2", "4"])
+def test_pipe_handover_of_running_clusters(O, template, slots, monkeypatch):
+    """A launch that has the GPU to itself lets workgroups that ran out of clusters take over RUNNING ones from workgroups
+    that still have several (k_icp.hip, pipe_give / pipe_wait_for_cluster: the cluster's points and neighbour indices cross to
+    another CU, possibly another XCD, in the middle of its ICP).  31 clusters on 8 workgroups (measured: 4-11 hand-overs per
+    call): the hand-overs must happen
+    (cd_timing.icp_handovers), and the records must be the oracle's and byte-identical to a launch without hand-overs."""
+    idx = list(range(60, 76))
+    frames = np.stack([synth.frame(i) for i in idx], 0)
+    prm = capi.default_params()
+    want = _oracle_records(O, frames, prm, template)
+    assert sum(r.n_clusters for r in want) >= 24
+    monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    monkeypatch.setenv("CUBOID_ICP_MAX_WG", "8")
+    monkeypatch.setenv("CUBOID_ICP_SLOTS", slots)
+    got = {}
+    for donate in ("1", "0"):
+        monkeypatch.setenv("CUBOID_ICP_DONATE", donate)
+        ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+        try:
+            ctx.set_template(0, template)
+            handovers = 0
+            for rep in range(3):                  # (the control block and the mailbox are reused from call to call)
+                res, _, _ = ctx.process_batch(frames, prm)
+                assert ctx.timing().icp_kernel_launches == 1
+                handovers += ctx.timing().icp_handovers
+                for f in range(len(frames)):
+                    assert_record_matches_oracle(res[f], want[f], (donate, rep, idx[f]))
+            got[donate] = (capi.results_to_array(res).copy(), handovers)
+        finally:
+            ctx.close()
+    assert got["0"][1] == 0 and got["1"][1] > 0, "no cluster changed workgroup: the test does not reach the hand-over path"
+    assert np.array_equal(got["0"][0], got["1"][0])

@@ -25,6 +25,9 @@ for f in range(F):
         if c.size >= 3:
             cl.append((c.size, c.iterations, float(np.linalg.norm(np.array(c.pose).reshape(4, 4)[:3, 3])), float(np.degrees(np.arccos(np.clip((np.trace(np.array(c.pose).reshape(4, 4)[:3, :3]) - 1) / 2, -1, 1))))))
 cl.sort(key=lambda t: -t[0])
+import json
+os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out'), exist_ok=True)
+json.dump([[c[0], c[1]] for c in cl], open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'cluster_costs.json'), 'w'))
 n = np.array([c[0] for c in cl], float); it = np.array([c[1] for c in cl], float)
 cost = np.ceil(n / 64) * (it + 1)
 M = len(cl)
