@@ -569,7 +569,7 @@ def main():
         # (3) BASELINE config 5: 1 M-point frames, five cuboids, five templates, every cluster against every template
         try:
             from perception_amd import synth
-            F5, M5, K5 = len(frames_c5), 4, 16
+            F5, M5, K5 = len(frames_c5), 4, 64   # (64 steps of ~25 ms: with 16 the fill and drain of the four-deep pipeline were a quarter of the clock)
             tpl5 = {k: templates.template_xyz32(L, W, H, dd) for k, (L, W, H, dd) in enumerate(synth.CONFIG5_DIMS)}
             prm5 = capi.default_params()
             prm5.rgb_offset = 12
