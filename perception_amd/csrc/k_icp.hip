@@ -1534,7 +1534,9 @@ struct PipeSlot {
     int arrived;                    // waves that finished their share of the current step
     int epoch;                      // steps completed (solved) so far
     int next_pass;                  // next 64-point pass of the current step nobody has taken yet
-    int give;                       // 1: the cluster is promised to a waiting workgroup - this step's stores are fenced at agent scope, then it goes
+    int give;                       // 1: the cluster is promised to a waiting workgroup - this step's stores of its points and neighbour indices go
+                                    // through to memory (agent scope), then it leaves
+    int take;                       // 1: the cluster has just arrived from another workgroup - this step reads them past L1 / L2 (agent scope)
 };
 
 // Umeyama + convergence test of one iteration (lane 0 of the finishing wave); same code as k_icp_solve.
@@ -1571,7 +1573,7 @@ __device__ __noinline__ int pipe_solve(PipeSlot* sl, const IcpParams& prm) {
 // (items [gbeg, gend) of `order`: the clusters that share the workgroup's template)
 __device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, const int* order, const IcpCluster* cl, const IcpState* st, int* queue,
                                             int* don) {
-    sl->give = 0;
+    sl->give = 0; sl->take = 0;
     for (;;) {
         const int item = gbeg + atomicAdd(queue, 1);
         if (item >= gend) { sl->phase = PH_EXHAUSTED; return; }
@@ -1595,17 +1597,48 @@ __device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, co
 // has two or more clusters going gives one of them away:
 //   waiter : DON_AVAIL += 1, then polls the mailbox (and DON_FINISHED == clusters of the launch -> ends)
 //   donor  : at a step boundary sees DON_AVAIL > 0, takes one (DON_AVAIL -= 1: one promise per waiter) and sets the slot's `give`;
-//            during the NEXT step every wave fences its stores of the cluster's points and neighbour indices at AGENT scope
-//            before it arrives (they must reach memory: the taker may sit on another XCD, whose L2 is not coherent with this
-//            one); at the end of that step the finishing wave writes the slot's IcpState to st[], fences, and publishes the
-//            cluster id in the next mailbox entry.  (A cluster that converged in that very step is not handed over: the
-//            promise is returned, DON_AVAIL += 1.)
-//   taker  : acquires the entry (agent-scope fence: its CU's L1 and its XCD's L2 drop what they hold), reloads the state,
-//            and carries on from iteration so.iters - the arithmetic does not depend on who executes it, so the records are
-//            bit-identical with or without hand-overs (tests/test_gpu_timed_path.py).
+//            during the NEXT step every wave writes the cluster's points and neighbour indices with agent-scope (sc1) stores -
+//            through to memory: the taker may sit on another XCD, whose L2 is not coherent with this one - and waits for them
+//            (vmcnt) before it arrives; at the end of that step the finishing wave writes the slot's IcpState to st[] the same
+//            way, waits, and publishes the cluster id in the next mailbox entry.  (A cluster that converged in that very step
+//            is not handed over: the promise is returned, DON_AVAIL += 1.)
+//   taker  : reads the entry and the state with agent-scope loads, sets the slot's `take`: in the cluster's FIRST step here every
+//            wave reads its points and indices with agent-scope loads (past this CU's L1 and this XCD's L2, which may hold
+//            lines from an earlier stay of the cluster); that step rewrites every point and index, so plain accesses are right
+//            again from the second step on.  The arithmetic does not depend on who executes it: the records are bit-identical
+//            with or without hand-overs (tests/test_gpu_timed_path.py).
+// (First version: agent-scope FENCES - every wave of the give step wrote back its XCD's whole L2, the taker invalidated its own.
+//  Same time, but the launch's HBM traffic went from 0.26 to 0.48 GB; profiles/r04_handover.txt.)
 // Nobody ever waits for a donor or a taker: donors never block, and a waiter's poll ends when every cluster is finished,
 // which the running workgroups reach on their own.  Both polls carry a bound all the same.
 __device__ __forceinline__ int don_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// agent-scope (sc1) accesses of a cluster's points and neighbour indices: written through to memory / read past this CU's L1
+// and this XCD's L2, dword by dword (relaxed atomics: the orderings come from s_waitcnt and the mailbox entry)
+__device__ __forceinline__ void store_agent(float4* p, const float4& v) {
+    unsigned* u = reinterpret_cast<unsigned*>(p);
+    __hip_atomic_store(u + 0, __float_as_uint(v.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 1, __float_as_uint(v.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 2, __float_as_uint(v.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(u + 3, __float_as_uint(v.w), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float4 load_agent(const float4* p) {
+    const unsigned* u = reinterpret_cast<const unsigned*>(p);
+    const unsigned x = __hip_atomic_load(u + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), y = __hip_atomic_load(u + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned z = __hip_atomic_load(u + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), w = __hip_atomic_load(u + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return make_float4(__uint_as_float(x), __uint_as_float(y), __uint_as_float(z), __uint_as_float(w));
+}
+// the slot's IcpState to / from st[] the same way (lane 0; 40 dwords)
+__device__ __forceinline__ void state_store_agent(IcpState* dst, const IcpState& src) {
+    static_assert(sizeof(IcpState) % 4 == 0, "IcpState is copied dword by dword");
+    unsigned* d = reinterpret_cast<unsigned*>(dst);
+    const unsigned* s = reinterpret_cast<const unsigned*>(&src);
+    for (int i = 0; i < (int)(sizeof(IcpState) / 4); ++i) __hip_atomic_store(d + i, s[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void state_load_agent(IcpState& dst, const IcpState* src) {
+    unsigned* d = reinterpret_cast<unsigned*>(&dst);
+    const unsigned* s = reinterpret_cast<const unsigned*>(src);
+    for (int i = 0; i < (int)(sizeof(IcpState) / 4); ++i) d[i] = __hip_atomic_load(s + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ int pipe_active_slots(const PipeSlot* slots) {
     int a = 0;
     for (int i = 0; i < PIPE_SLOTS; ++i) a += (slots[i].phase == PH_ITER || slots[i].phase == PH_FIT) ? 1 : 0;
@@ -1615,12 +1648,11 @@ __device__ __forceinline__ int pipe_active_slots(const PipeSlot* slots) {
 __device__ __noinline__ bool pipe_give(PipeSlot* sl, const PipeSlot* slots, IcpState* st, int* don) {
     bool gone = false;
     if (pipe_active_slots(slots) >= 2) {
-        st[2 * (size_t)sl->k] = sl->so;
-        st[2 * (size_t)sl->k + 1] = sl->so;
-        __threadfence();
+        state_store_agent(&st[2 * (size_t)sl->k], sl->so);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the state is in memory before the entry says so
         const int t = __hip_atomic_fetch_add(don + DON_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < DON_CAP) {
-            __hip_atomic_store(don + DON_BOX + t, sl->k + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(don + DON_BOX + t, sl->k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gone = true;
         }
     }
@@ -1637,8 +1669,7 @@ __device__ __noinline__ int pipe_wait_for_cluster(int* don, int total) {
             int expect = head;
             if (__hip_atomic_compare_exchange_strong(don + DON_HEAD, &expect, head + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 int v = 0;
-                for (int spins = 0; spins < (1 << 24) && v == 0; ++spins) v = __hip_atomic_load(don + DON_BOX + head, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-                __threadfence();
+                for (int spins = 0; spins < (1 << 24) && v == 0; ++spins) v = don_load(don + DON_BOX + head);
                 return v - 1;   // (-1 only if the entry never appeared: its writer increments DON_TAIL and stores the entry back to back)
             }
             continue;
@@ -1738,7 +1769,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
         for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) {
             PipeSlot* sl = &s_slot[sidx];
             for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
-            sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0; sl->give = 0;
+            sl->arrived = 0; sl->epoch = 0; sl->it = 0; sl->n = 0; sl->src_off = 0; sl->k = 0; sl->next_pass = 0; sl->give = 0; sl->take = 0;
             sl->phase = sidx < prm.pipe_slots ? PH_FILL : PH_EXHAUSTED;   // (a slot the launch does not use is dropped at its first visit)
         }
         // slot 0 starts with a cluster; the other slots are filled at their first step (PH_FILL), after every workgroup took its first
@@ -1768,6 +1799,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             const int phase = sl->phase;
             if (phase == PH_EXHAUSTED) { live &= ~(1u << sidx); continue; }
             const int give = sl->give;   // the cluster leaves this workgroup after this step: its stores must reach memory
+            const int take = sl->take;   // it arrived before this step: its points and indices are read from memory
             if (phase == PH_ITER || phase == PH_FIT) {
                 const int it = sl->it, n = sl->n;
                 float4* pts = src + sl->src_off;
@@ -1806,16 +1838,17 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     }
 #endif
                     if (lane < nk) {
-                        const float4 p = pts[myq];
+                        const float4 p = take ? load_agent(&pts[myq]) : pts[myq];
                         if (phase == PH_ITER) {
                             q.px = p.x; q.py = p.y; q.pz = p.z;
                             if (it > 0) {   // X <- T*X, written back by the lane that owns the point
                                 xform(sl->so.T, p.x, p.y, p.z, q.px, q.py, q.pz);
-                                pts[myq] = make_float4(q.px, q.py, q.pz, p.w);
+                                if (give) store_agent(&pts[myq], make_float4(q.px, q.py, q.pz, p.w));
+                                else pts[myq] = make_float4(q.px, q.py, q.pz, p.w);
                             }
                             q.pbest = 3.402823466e38f;
                             if (it > 0) {
-                                q.pbi = nnq[myq];
+                                q.pbi = take ? don_load(&nnq[myq]) : nnq[myq];
                                 const float4 q0p = BIG ? tp[(unsigned)q.pbi] : s_tpl[q.pbi];
                                 q.pbest = dist2(q.px, q.py, q.pz, q0p.x, q0p.y, BIG ? q0p.z : q0p.w);
                                 kw = BIG ? (((unsigned)__float_as_int(q0p.w) << 16) | (unsigned)q.pbi) : (unsigned)__float_as_int(q0p.z);
@@ -1894,7 +1927,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     const bool fast = ballot64(lane < nk && !(big_c < 256.f && q.pbest < 16384.f)) == 0ull;
                     if (lane < nk) {
                         if (phase == PH_ITER) {
-                            nnq[myq] = q.pbi;
+                            if (give) __hip_atomic_store(&nnq[myq], q.pbi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            else nnq[myq] = q.pbi;
                             if (fast) {
 #pragma unroll
                                 for (int a = 0; a < 3; ++a) {
@@ -1923,7 +1957,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                 }
                 CD_PHASE(5)
             }
-            if (give) __threadfence(); else __threadfence_block();
+            if (give) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the write-through stores of this wave have landed)
+            __threadfence_block();
             int a = 0;
             if (lane == 0) a = atomicAdd(&sl->arrived, 1);
             a = __builtin_amdgcn_readfirstlane(a);
@@ -1933,6 +1968,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     if (phase == PH_ITER) {
                         // (the load is in flight while the step is solved)
                         const int waiting = don ? don_load(don + DON_AVAIL) : 0;
+                        sl->take = 0;
                         if (pipe_solve(sl, prm)) {
                             sl->phase = PH_FIT;
                             if (sl->give) { sl->give = 0; __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }   // converged: stays
@@ -1987,8 +2023,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             PipeSlot* sl = &s_slot[0];
             const IcpCluster c = cl[k];
             sl->src_off = c.src_off; sl->n = c.n; sl->k = k;
-            sl->so = st[2 * (size_t)k];
-            sl->phase = PH_ITER; sl->it = sl->so.iters; sl->give = 0;
+            state_load_agent(sl->so, &st[2 * (size_t)k]);
+            sl->phase = PH_ITER; sl->it = sl->so.iters; sl->give = 0; sl->take = 1;
             for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
             sl->arrived = 0; sl->next_pass = 0;
         }
