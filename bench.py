@@ -244,15 +244,16 @@ def main():
     ap.add_argument("--inflight", type=int, default=None,
                     help="batches in flight per GPU: each has its own context (stream + device arena) and host thread, so the "
                          "front end of batch i+1 fills the CUs that the tail of batch i's ICP leaves idle (1 = strictly serial; "
-                         "default 5 (a long run gains 2-3 %% more from 6, a 20-step run loses as much to the longer fill and drain), config 5: 4 - "
-                         "measured, DESIGN.md section 6)")
+                         "default for config 3: 7 for runs of 60 steps or more (59.7 / 60.6 / 61.4-62.2 k frames/s with 5 / 6 / 7, 50 k with "
+                         "8 and more: profiles/r04_sweep_inflight.txt), 5 for shorter runs, whose clock is mostly fill and drain (the driver's "
+                         "20-step shape reads the same with 5 and 7); config 5: 4 - measured, DESIGN.md section 6)")
     args = ap.parse_args()
     if args.frames is None:
         args.frames = 256 if args.config == 3 else 64
     if args.steps is None:
         args.steps = 300 if args.config == 3 else 12
     if args.inflight is None:
-        args.inflight = 5 if args.config == 3 else 4
+        args.inflight = (7 if args.steps >= 60 else 5) if args.config == 3 else 4
     if args.steps < 1 or args.warmup < 0 or args.frames < 1:
         raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 
