@@ -21,7 +21,13 @@ import time
 # config 5's six batches have two low-priority ICP streams each, and with 8 queues four of those twelve streams share
 # one (rocprofv3 kernel trace: a batch's k_icp_pipe starts when another batch's k_icp_pipe_big ends) - 16 there.  Must be
 # set before the HIP runtime initialises: main() does it once the arguments are known.
-DEFAULT_HW_QUEUES = {3: "16", 5: "16"}   # (config 3 measures the same with 8 and with 16: profiles/r03_ab_hwq.txt; its config-5 leg wants 16)
+# But the queues of a PROCESS are a budget too (round 4): every context has one normal-priority stream and two low-priority
+# ones, each class capped at GPU_MAX_HW_QUEUES, queues of closed contexts stay with the process, and from ~24 hardware queues
+# on the GPU time-slices them - with seven contexts for the headline and 16 queues per class the legs that create their own
+# contexts afterwards lost a quarter (config-5 leg 1.85 k instead of 2.5 k frames/s, big template 12.0 instead of 11.0 ms;
+# eight contexts in the headline itself: 50 k instead of 61 k).  10 per class keeps the whole default run below the limit
+# (headline 61.0 k, legs 2.51 k / 11.1 ms; with 12: 61.7 k / 2.42 k / 11.0; with 8: 59.1 k) - profiles/r04_sweep_inflight.txt.
+DEFAULT_HW_QUEUES = {3: "10", 5: "16"}
 
 import numpy as np
 
@@ -568,8 +574,8 @@ def main():
         except Exception as e:
             legs_out["big_template_ms"] = {"error": repr(e)}
         # (3) BASELINE config 5: 1 M-point frames, five cuboids, five templates, every cluster against every template.  The headline's
-        # pipeline is closed first: nine contexts' streams share the process's hardware queues, and with the five idle ones still
-        # open this leg read 1.8 k frames/s where the same workload alone reads 2.4-2.5 k.
+        # pipeline is closed first (its arenas are not needed any more; what slowed this leg down was the process's hardware-queue
+        # budget, see DEFAULT_HW_QUEUES).
         pipe.close()
         pipe = None
         try:
