@@ -505,7 +505,8 @@ def main():
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
         serial_rec = capi.results_to_array(res).copy()
         serial_t = ctx.timing()
-        if M > 1:   # (once more for the timing: the first pass after the pipelined region still finds the other contexts' data in L2)
+        for _ in range(4 if M > 1 else 0):   # (a few more for the timing: the first pass after the pipelined region still finds the
+            # other contexts' data in L2, and a lone launch varies by ~3 % from one to the next; the fastest of five is kept)
             ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
             t2 = ctx.timing()
             if 0 < t2.icp_kernel_ms < serial_t.icp_kernel_ms:
@@ -684,7 +685,10 @@ def main():
                              "note": "pipe_frac = B / B_at_saturation = A / A_at_saturation: the share of the saturated f32 vector rate (independent "
                                      "v_fma_f32, four waves per SIMD) this kernel issues; against a stream of its own instruction mix (LDS reads, 64-bit "
                                      "key minima) pipe_frac_vs_search_mix.  Round 3 printed A as 'issue_frac 0.86': A reads 2.36, not 1.0, when the "
-                                     "pipe is full"})
+                                     "pipe is full.  The counters are of ONE launch alone on the GPU, which since the second half of round 4 keeps "
+                                     "the workgroups that ran out of clusters waiting inside the launch (hand-overs): their parked waves count in "
+                                     "SQ_WAVE_CYCLES (8.2e9 -> 1.0e10 for the same 1.95e9 vector instructions), so the per-wave-cycle rates read a "
+                                     "fifth lower than the 0.40 of a launch whose idle workgroups end"})
                 pf = valu["pipe_frac"]
                 bound = "valu" if pf >= 0.8 else "latency"
             wname, wpath = _first_profile(ICP_WORK_FILES)
@@ -720,7 +724,7 @@ def main():
                          "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
                          "traffic_note": "HBM bytes of one launch from the committed counter file (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                          "this workload, gfx950 x2 FETCH correction; counters cannot be collected inside this run)",
-                         "avg_launch_ms": head_ms, "avg_launch_ms_is": "one launch alone on an idle GPU (serial pass after the timed region)" if excl_ms is not None else
+                         "avg_launch_ms": head_ms, "avg_launch_ms_is": "one launch alone on an idle GPU (fastest of five serial passes after the timed region)" if excl_ms is not None else
                                                                         "launches of the timed region (no serial pass: --no-verify)",
                          "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
