@@ -1911,6 +1911,14 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                     search_patches<true>(s_tpl, s_kd, bx, tpl_m, q, ballot64(lane < nk && !near), psplit, &s_far[wave]);
 #endif
                     }
+#ifdef CD_STATS
+                    {   // far queries whose TRUE neighbour lies within the grid walk's reach (a better seed would have made them near), by iteration class
+                        const unsigned long long far_ = ballot64(lane < nk && !near && phase == PH_ITER);
+                        const unsigned long long conv_ = ballot64(lane < nk && !near && phase == PH_ITER && __fmul_rn(__fsqrt_rn(q.pbest), 1.0f + 2.0e-6f) <= rmax);
+                        const int cls_ = it < 3 ? 0 : it < 16 ? 1 : 2;
+                        if (lane == 0) { atomicAdd(&g_icp_stats[9 + cls_], (unsigned long long)__popcll(conv_)); atomicAdd(&g_icp_stats[12 + cls_], (unsigned long long)__popcll(far_)); }
+                    }
+#endif
                     CD_PHASE(4)
                     // The pass's 16 moment terms go into the slot's accumulators right away: no sum is carried in registers
                     // across the searches (32 VGPRs that the search loops would otherwise spill around).
