@@ -146,3 +146,34 @@ def test_pipe_handover_of_running_clusters(O, template, slots, monkeypatch):
             ctx.close()
     assert got["0"][1] == 0 and got["1"][1] > 0, "no cluster changed workgroup: the test does not reach the hand-over path"
     assert np.array_equal(got["0"][0], got["1"][0])
+
+
+def test_pipe_big_handover_of_running_clusters(O, monkeypatch):
+    """The same hand-over in k_icp_pipe_big (the template stays in global memory: the reference's 21 400-point six-face cuboid):
+    records with hand-overs forced on equal the oracle's and the bytes of a launch without them."""
+    from conftest import GOLDEN
+    from perception_amd import pcd
+    big = pcd.read_xyz(os.path.join(GOLDEN, "template_cuboid_L200_W100_H75.pcd")).astype(np.float32)
+    idx = list(range(60, 72))
+    frames = np.stack([synth.frame(i) for i in idx], 0)
+    prm = capi.default_params()
+    want = _oracle_records(O, frames, prm, big)
+    monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    monkeypatch.setenv("CUBOID_ICP_MAX_WG", "8")
+    got = {}
+    for donate in ("1", "0"):
+        monkeypatch.setenv("CUBOID_ICP_DONATE", donate)
+        ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+        try:
+            ctx.set_template(0, big)
+            handovers = 0
+            for rep in range(2):
+                res, _, _ = ctx.process_batch(frames, prm)
+                handovers += ctx.timing().icp_handovers
+                for f in range(len(frames)):
+                    assert_record_matches_oracle(res[f], want[f], ("big", donate, rep, idx[f]))
+            got[donate] = (capi.results_to_array(res).copy(), handovers)
+        finally:
+            ctx.close()
+    assert got["0"][1] == 0 and got["1"][1] > 0, "no cluster changed workgroup"
+    assert np.array_equal(got["0"][0], got["1"][0])
