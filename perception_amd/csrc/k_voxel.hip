@@ -685,7 +685,6 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                 ig = __builtin_amdgcn_udot4(u, 0x00000100u, ig, false);                                \
                 ib = __builtin_amdgcn_udot4(u, 0x00000001u, ib, false);                                \
             }                                                                                          \
-            ++cnt;                                                                                     \
         }
 #define CD_RUN(I, P, Q)                                                                                \
         if (len##I > 0) {                                                                              \
@@ -718,6 +717,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
             uint32_t kk2 = 0, rec2 = 0;
             const bool have2 = len3 > 0 && eb + 4 + ql < n;
             if (have2) { kk2 = k[eb + 4 + ql]; rec2 = v[eb + 4 + ql]; }
+            cnt += (len0 + len1) + (len2 + len3);   // (the voxel's point count is the sum of its runs' lengths: not counted point by point)
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
             if (ql < len0) p0 = cpt[fbase + start0 + ql];
             if (ql < len1) p1 = cpt[fbase + start1 + ql];
