@@ -229,7 +229,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=None, help="GPUs of this node to use, one rank process per GPU (default: WORLD_SIZE or 1)")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 300, about 2.5 s of timed region)")
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps before the clock starts (default: one per batch in flight, at least 4, so that every context has run once)")
     ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (BASELINE config 3: 256; config 5: 64 - the config names no batch size; 8 was round 2's choice, tools/sweep_c5_frames.sh)")
     ap.add_argument("--config", type=int, default=3, choices=(3, 5),
                     help="3: the headline workload (256 D435 frames per GPU, one template); 5: the multi-template stress of "
@@ -260,6 +260,8 @@ def main():
         args.steps = 300 if args.config == 3 else 12
     if args.inflight is None:
         args.inflight = (7 if args.steps >= 60 else 5) if args.config == 3 else 4
+    if args.warmup is None:
+        args.warmup = max(4, args.inflight)
     if args.steps < 1 or args.warmup < 0 or args.frames < 1:
         raise SystemExit("bench.py: --steps/--frames must be >= 1, --warmup >= 0")
 
