@@ -173,6 +173,25 @@ const char* cd_last_error(const cd_context* ctx);
  * template is uploaded once and stays device-resident. */
 int cd_set_template(cd_context* ctx, int slot, const void* xyz, size_t stride_bytes, int m);
 
+/* What cd_set_template found: the number of lattice faces of the slot's template, 0 when it is an arbitrary cloud (negative
+ * cd_status on a bad slot).  cuboid_detection/templates/make_cuboid.py:38-55 writes every cuboid template as faces that are
+ * Cartesian products of shared axis tables; cd_set_template verifies that structure bit by bit and, when it holds, the ICP
+ * finds nearest neighbours in closed form instead of searching (same neighbour, same lowest-index tie rule). */
+int cd_template_lattice_faces(const cd_context* ctx, int slot);
+
+/* The correspondence search of icp.align on its own (pcl::registration::CorrespondenceEstimation -> KdTreeFLANN
+ * nearestKSearch(k = 1), behind icp.cpp:178 / opd.cpp:228): for each of n query points the ORIGINAL index of the nearest
+ * point of the slot's template (ties: lowest index) and the squared distance, float32, (dx*dx + dy*dy) + dz*dz.  Runs the
+ * closed-form lattice search; CD_ERR_INVALID_ARG for a template that is not a lattice (its searches only exist inside the ICP
+ * kernels). */
+int cd_template_nearest(cd_context* ctx, int slot, const void* queries, size_t stride_bytes, int n, int32_t* out_index,
+                        float* out_d2);
+
+/* Host-only (no context, no GPU): the lattice test of cd_set_template.  out (may be NULL) receives up to 8 faces x
+ * {constant axis, fast axis, first index, points along the fast axis, points along the slow axis}.  Returns the number of
+ * faces, 0 = not a lattice. */
+int cd_lattice_detect(const void* xyz, size_t stride_bytes, int m, int32_t* out);
+
 /* S0+S1: two PassThrough filters + VoxelGrid::filter (gps.cpp:53-73).  out_xyz receives
  * N_v * 3 floats in ascending voxel-index order, out_rgb (may be NULL) N_v packed rgb. */
 int cd_crop_voxel(cd_context* ctx, const void* points, size_t stride_bytes, int n,
@@ -318,7 +337,10 @@ typedef struct cd_timing {
     int32_t icp_handovers;                        /* running clusters that changed workgroup inside that launch (a call that has the GPU to
                                                    * itself lets workgroups without work take over clusters from those that still have
                                                    * several: scheduling only, results do not depend on it)                             */
-    int32_t reserved;
+    int32_t icp_search;                           /* which nearest-neighbour search the ICPs of this call ran: 0 the pruned searches over an
+                                                   * arbitrary template, 1 the closed form for a template that is a union of axis-aligned
+                                                   * lattices (every make_cuboid.py template; cd_template_lattice_faces), 2 both (mixed batch).
+                                                   * Results do not depend on it                                                            */
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

@@ -31,6 +31,7 @@ EXPORTED_SYMBOLS = [
     "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_extract", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_frame", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing", "cd_get_frame_cloud", "cd_get_cluster_points", "cd_ground_plane", "cd_set_frame_guesses",
+    "cd_template_lattice_faces", "cd_template_nearest", "cd_lattice_detect",
 ]
 
 CD_CLOUD_VOXELS, CD_CLOUD_OBJECTS = 0, 1
@@ -94,7 +95,7 @@ class CdTiming(C.Structure):
         ("icp_pair_tests_lo", C.c_int32), ("icp_pair_tests_hi", C.c_int32), ("icp_persist_gave_up", C.c_int32),
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
         ("scan_retries", C.c_int32), ("icp_regime", C.c_int32),
-        ("icp_handovers", C.c_int32), ("reserved", C.c_int32),
+        ("icp_handovers", C.c_int32), ("icp_search", C.c_int32),
     ]
 
 
@@ -178,6 +179,9 @@ def load_library(path=None):
     lib.cd_get_cluster_points.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, C.c_size_t, C.c_int, ip]
     lib.cd_ground_plane.argtypes = [vp, vp, C.c_size_t, C.c_int, C.POINTER(CdParams), f32p, vp, C.c_int, ip, ip]
     lib.cd_set_frame_guesses.argtypes = [vp, f32p, C.c_int]
+    lib.cd_template_lattice_faces.argtypes = [vp, C.c_int]
+    lib.cd_template_nearest.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
+    lib.cd_lattice_detect.argtypes = [vp, C.c_size_t, C.c_int, vp]
     if path is None:
         _lib = lib
     return lib
@@ -390,10 +394,33 @@ class Context:
         g = np.ascontiguousarray(guesses, np.float32).reshape(-1, 16)
         self._check(self.lib.cd_set_frame_guesses(self.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.shape[0]))
 
+    def template_lattice_faces(self, slot):
+        """Faces of the slot's template as a union of axis-aligned lattices (make_cuboid.py's output); 0 = an arbitrary cloud."""
+        return self._check(self.lib.cd_template_lattice_faces(self.h, slot), ok=tuple(range(0, 9)))
+
+    def template_nearest(self, slot, queries):
+        """Nearest template point of every query: (original index int32, squared distance float32).  Lattice templates only."""
+        a, stride, n = _points(queries)
+        idx = np.empty(max(n, 1), np.int32)
+        d2 = np.empty(max(n, 1), np.float32)
+        self._check(self.lib.cd_template_nearest(self.h, slot, _ptr(a), stride, n, _ptr(idx), _ptr(d2)))
+        return idx[:n], d2[:n]
+
     def timing(self):
         t = CdTiming()
         self._check(self.lib.cd_get_timing(self.h, C.byref(t)))
         return t
+
+
+def lattice_detect(xyz):
+    """Host-only lattice test of cd_set_template: list of faces (constant axis, fast axis, first index, n_fast, n_slow)."""
+    lib = load_library()
+    a, stride, m = _points(xyz)
+    out = np.zeros((8, 5), np.int32)
+    nf = lib.cd_lattice_detect(_ptr(a), stride, m, _ptr(out))
+    if nf < 0:
+        raise CuboidError(nf, "cd_lattice_detect")
+    return [tuple(int(v) for v in out[f]) for f in range(nf)]
 
 
 def results_to_array(res):

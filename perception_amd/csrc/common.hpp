@@ -126,6 +126,27 @@ struct IcpSuper {
     float lo[64][4], hi[64][4];   // box
 };
 
+// A template that is a union of axis-aligned LATTICES (every make_cuboid.py template: face k = the Cartesian product of two
+// of three shared axis tables X, Y, Z at a constant third coordinate, written first-axis-fastest, mkc.py:38-55).  Detected
+// and verified bit by bit against the uploaded points by cd_set_template (lattice_detect, cuboid_hip.hip); the nearest
+// neighbour of a query is then a closed form over the axis tables (k_icp_lat.hip) - no search structure, no template image.
+constexpr int LAT_MAX_FACES = 6;           // (a cuboid has six)
+constexpr int LAT_MAX_TAB = 736;           // axis table entries of one template, the three axes together
+struct IcpLattice {
+    int32_t nface;                 // 0: not a lattice - the generic searches of k_icp.hip take the template
+    int32_t ntab;                  // entries of tab in use
+    int32_t n[3];                  // entries of the axis tables X, Y, Z (0: no face varies along that axis)
+    int32_t toff[3];               // first entry of each table in tab
+    float o[3], inv[3];            // T[0] of each table and 1 / step (the tables are uniform to 1/16 of a step: index guess)
+    int32_t w[LAT_MAX_FACES];      // the face's constant axis
+    int32_t fast[LAT_MAX_FACES];   // the axis whose index varies fastest: index = base + i_slow * n[fast] + i_fast
+    int32_t base[LAT_MAX_FACES];   // original index of the face's first point (faces are consecutive, ascending)
+    float c[LAT_MAX_FACES];        // its constant coordinate
+    uint32_t m0[LAT_MAX_FACES], m1[LAT_MAX_FACES], m2[LAT_MAX_FACES];   // all ones when w == 0 / 1 / 2 (the face loop's selects are v_bfi_b32 with these
+                                   // words); faces beyond nface: a constant z = NaN, so that their "distance" is NaN and never compares below anything
+    float4 tab[LAT_MAX_TAB];       // entry i of a table: (T[i-1], T[i], T[i+1], unused) with T[-1] = -inf, T[n] = +inf
+};
+
 struct IcpState {          // dynamic ICP state, double-buffered by launch parity
     float Tfinal[16];
     float T[16];           // transformation_ of the current iteration

@@ -88,6 +88,10 @@ struct cd_context {
     bool tpl_gridded[CD_MAX_TEMPLATES] = {false};                // slot has a cell start table
     bool tpl_big[CD_MAX_TEMPLATES] = {false};                    // slot does not fit LDS but has what k_icp_pipe_big needs (cell table, k-d map, superpatches)
     IcpSuper* d_super = nullptr;                                  // per template slot
+    IcpLattice* d_lat = nullptr;                                  // per template slot: axis tables and faces of a lattice template (nface = 0: none)
+    int tpl_faces[CD_MAX_TEMPLATES] = {0};                        // faces of the slot's lattice (0: the generic searches take it)
+    int icp_lattice = 1;                                          // CUBOID_ICP_LATTICE=0: lattice templates take the generic searches too (A/B, fallback tests)
+    int lat_threads = 0;                                          // CUBOID_LAT_THREADS: workgroup size of k_icp_lat (256 / 512 / 1024; 0 = by the launch's shape)
     hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
                                                                   // first (stream2); with icp_lowprio both are low-priority streams, so that CUs that come free go to the
                                                                   // short front-end kernels of the other batches in flight before the next persistent workgroup
@@ -601,11 +605,24 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         if (cl.tpl_m <= ICP_TPL_LDS) return 1;
         return c->tpl_big[cl.slot] ? 2 : 0;
     };
+    // Clusters whose template is a lattice (every make_cuboid.py template; IcpLattice, common.hpp) go to k_icp_lat - closed-form
+    // nearest neighbour, one workgroup per cluster - and take no part in the grouping below.  CUBOID_ICP_LATTICE=0 and the
+    // forced driver modes (CUBOID_ICP_MODE) keep them on the generic searches (A/B, and the GPU suite runs under each mode).
+    const bool use_lat = c->icp_lattice != 0 && c->icp_mode == 0;
+    std::vector<char> in_lat((size_t)ncl, 0);
+    int n_lat = 0, n_live = 0, lat_max_n = 0;
+    for (int k = 0; k < ncl; ++k) {
+        const IcpCluster& cl = c->h_cl[k];
+        const bool live = cl.n >= 3 && cl.tpl_m > 0;
+        n_live += live ? 1 : 0;
+        if (use_lat && live && c->tpl_faces[cl.slot] > 0) { in_lat[(size_t)k] = 1; ++n_lat; lat_max_n = std::max(lat_max_n, cl.n); }
+    }
+    c->timing.icp_search = n_lat == 0 ? 0 : (n_lat == n_live ? 1 : 2);
     std::vector<TplGroup> groups;
     for (int k = 0; k < ncl; ++k) {
         const IcpCluster& cl = c->h_cl[k];
         if (groups.empty() || c->h_cl[groups.back().beg].tpl_off != cl.tpl_off || c->h_cl[groups.back().beg].tpl_m != cl.tpl_m)
-            groups.push_back(TplGroup{k, k, 0, kind_of(cl), 0});
+            groups.push_back(TplGroup{k, k, 0, use_lat && c->tpl_faces[cl.slot] > 0 ? 0 : kind_of(cl), 0});
         TplGroup& g = groups.back();
         g.end = k + 1;
         if (cl.n >= 3) { g.live += 1; g.pts += cl.n; }
@@ -626,7 +643,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     for (int k = 0; k < ncl; ++k) {
         IcpCluster& cl = c->h_cl[k];
         cl.tile0 = nwork;
-        const int tiles = cl.n >= 3 && cl.tpl_m > 0 && !in_pipe[(size_t)k] ? (cl.n + qslice - 1) / qslice : 0;
+        const int tiles = cl.n >= 3 && cl.tpl_m > 0 && !in_pipe[(size_t)k] && !in_lat[(size_t)k] ? (cl.n + qslice - 1) / qslice : 0;
         if (nwork + tiles > c->work_cap) return fail(c, CD_ERR_CAPACITY, "ICP work list overflow");
         for (int t = 0; t < tiles; ++t) c->h_work[nwork++] = IcpWork{k, t};
         for (int s = 0; s < 2; ++s) {
@@ -673,6 +690,43 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         return std::min(cap, std::max(32, (n_items / ip.pipe_slots + 16) / 32 * 32));
     };
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
+    if (n_lat > 0) {
+        // one workgroup per cluster, largest first.  Workgroup size: four waves per cluster when the launch has clusters enough to
+        // fill the chip that way (a wave of a big batch then owns ~5 passes of 64 points per iteration and the per-iteration
+        // costs that do not shrink - two barriers, the fold of the moment sums, the single-lane solve - are paid by few waves),
+        // sixteen when there are few clusters or very large ones (latency: one frame; config 5's thousands of points)
+        int no = 0;
+        for (int k = 0; k < ncl; ++k) if (in_lat[(size_t)k]) c->h_order[no++] = k;
+        std::stable_sort(c->h_order, c->h_order + no, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
+        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
+        int threads = c->lat_threads;
+        if (threads <= 0) {
+            threads = n_lat >= 384 ? 256 : (n_lat >= 96 ? 512 : 1024);
+            if (lat_max_n > 16384) threads = 1024;
+            else if (lat_max_n > 4096) threads = std::max(threads, 512);
+        }
+        LAUNCH(c, launch_icp_lat(c->stream, n_lat, threads, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, ip));
+        c->timing.icp_kernel_launches = 1;
+        c->timing.icp_regime = (1 << 16) | std::min(n_lat, 0xffff);
+        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        if (n_lat == n_live) {
+            HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipStreamSynchronize(c->stream));
+            float ms1 = 0.f;
+            hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
+            c->timing.icp_kernel_ms = ms1;
+            if (pair_tests) {
+                long long tot = 0;
+                for (int k = 0; k < ncl; ++k)
+                    if (c->h_st[2 * k].status == CD_OK) tot += (long long)c->h_cl[k].n * c->h_cl[k].tpl_m * (c->h_st[2 * k].iters + 1);
+                *pair_tests = tot;
+            }
+            return CD_OK;
+        }
+        // mixed batch: the other clusters take the drivers below, which find these finished in d_st / h_st (the stream orders them)
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
     // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its
     // complete ICP (all iterations + fitness) inside one persistent workgroup, one launch for the batch.
     // The pipelined variant (two to four clusters in flight per workgroup, no barrier in the iteration loop) needs one
@@ -1298,6 +1352,7 @@ void cd_destroy(cd_context* c) {
     if (c->d_koffx) hipFree(c->d_koffx);
     if (c->d_guess) hipFree(c->d_guess);
     if (c->d_super) hipFree(c->d_super);
+    if (c->d_lat) hipFree(c->d_lat);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     for (auto& e : c->ev2) if (e) hipEventDestroy(e);
@@ -1349,6 +1404,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     c->tpl_cap = 1 << 18;
     ok = ok && dalloc(&c->d_tpl, (size_t)c->tpl_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_super, (size_t)CD_MAX_TEMPLATES) == hipSuccess;
+    ok = ok && dalloc(&c->d_lat, (size_t)CD_MAX_TEMPLATES) == hipSuccess;
     {
         const int prio = c->icp_lowprio ? prio_least : 0;
         ok = ok && hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, prio) == hipSuccess;
@@ -1374,6 +1430,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_DONATE")) c->icp_donate = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_ICP_LATTICE")) c->icp_lattice = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_LAT_THREADS")) c->lat_threads = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
@@ -1415,7 +1473,85 @@ struct PreparedTemplate {
     IcpGrid grid;                                        // cell_off is set per slot at upload
     IcpSuper super;                                      // second box level of a template that does not fit LDS (n = 0: none)
     bool big_ok = false;                                 // k_icp_pipe_big can search it
+    IcpLattice lat;                                      // nface > 0: the template is a union of axis-aligned lattices (k_icp_lat.hip)
 };
+
+// Is the template what make_cuboid.py writes (mkc.py:38-55) - faces one after the other, each the Cartesian product of two of
+// three shared, ascending, near-uniform axis tables at a constant third coordinate, first axis fastest?  Verified bit by bit
+// against the points; anything else (a point moved, a row missing, the object templates) leaves nface = 0.
+static void lattice_detect(const float* xyz, int m, IcpLattice* out) {
+    std::memset(out, 0, sizeof(*out));
+    struct Face { int w, u, v, base, nu, nv; float c; };
+    std::vector<Face> faces;
+    std::vector<float> tabs[3];
+    auto P = [&](int i, int a) { return xyz[3 * (size_t)i + a]; };
+    for (int i = 0; i < 3 * m; ++i) if (!std::isfinite(xyz[i])) return;
+    int pos = 0;
+    while (pos < m) {
+        if ((int)faces.size() >= LAT_MAX_FACES || pos + 1 >= m) return;
+        int u = -1;
+        for (int a = 0; a < 3; ++a)
+            if (P(pos + 1, a) != P(pos, a)) { if (u >= 0) return; u = a; }
+        if (u < 0) return;
+        int nu = 1;   // first row: only u moves, ascending
+        while (pos + nu < m && P(pos + nu, u) > P(pos + nu - 1, u) && P(pos + nu, (u + 1) % 3) == P(pos, (u + 1) % 3) &&
+               P(pos + nu, (u + 2) % 3) == P(pos, (u + 2) % 3)) ++nu;
+        if (nu < 2 || pos + nu >= m) return;
+        int v = -1;
+        for (int a = 0; a < 3; ++a)
+            if (P(pos + nu, a) != P(pos, a)) { if (v >= 0 || a == u) return; v = a; }
+        if (v < 0) return;
+        const int w = 3 - u - v;
+        int nv = 1;   // further rows: the same u values, v constant within the row and ascending from row to row, w constant
+        while (pos + (nv + 1) * nu <= m) {
+            const int r = pos + nv * nu;
+            bool ok = P(r, v) > P(r - nu, v);
+            for (int i = 0; i < nu && ok; ++i) ok = P(r + i, u) == P(pos + i, u) && P(r + i, v) == P(r, v) && P(r + i, w) == P(pos, w);
+            if (!ok) break;
+            ++nv;
+        }
+        if (nv < 2) return;
+        std::vector<float> U((size_t)nu), V((size_t)nv);
+        for (int i = 0; i < nu; ++i) U[(size_t)i] = P(pos + i, u);
+        for (int j = 0; j < nv; ++j) V[(size_t)j] = P(pos + j * nu, v);
+        const std::pair<int, std::vector<float>*> both[2] = {{u, &U}, {v, &V}};
+        for (const auto& av : both) {   // one table per axis, shared by every face that varies along it
+            if (tabs[av.first].empty()) tabs[av.first] = *av.second;
+            else if (tabs[av.first] != *av.second) return;
+        }
+        faces.push_back(Face{w, u, v, pos, nu, nv, P(pos, w)});
+        pos += nu * nv;
+    }
+    int ntab = 0;
+    for (int a = 0; a < 3; ++a) {
+        const std::vector<float>& T = tabs[a];
+        const int n = (int)T.size();
+        out->toff[a] = ntab;
+        if (n == 0) {   // no face varies along this axis: a one-entry table, so that the kernel treats every axis alike (never read by a face)
+            if (ntab + 1 > LAT_MAX_TAB) { std::memset(out, 0, sizeof(*out)); return; }
+            out->n[a] = 1; out->o[a] = 0.f; out->inv[a] = 1.f;
+            out->tab[ntab++] = make_float4(-INFINITY, 0.f, INFINITY, 0.f);
+            continue;
+        }
+        out->n[a] = n;
+        if (ntab + n > LAT_MAX_TAB) { std::memset(out, 0, sizeof(*out)); return; }
+        const double step = ((double)T[(size_t)n - 1] - (double)T[0]) / (double)(n - 1);
+        for (int i = 0; i < n; ++i)   // uniform to 1/16 of a step: the index guess of lat_axis is then at most one entry off
+            if (!(std::fabs((double)T[(size_t)i] - ((double)T[0] + i * step)) <= step / 16.0)) { std::memset(out, 0, sizeof(*out)); return; }
+        out->o[a] = T[0];
+        out->inv[a] = (float)(1.0 / step);
+        for (int i = 0; i < n; ++i)
+            out->tab[ntab + i] = make_float4(i > 0 ? T[(size_t)i - 1] : -INFINITY, T[(size_t)i], i + 1 < n ? T[(size_t)i + 1] : INFINITY, 0.f);
+        ntab += n;
+    }
+    out->ntab = ntab;
+    for (size_t f = 0; f < faces.size(); ++f) {
+        out->w[f] = faces[f].w; out->fast[f] = faces[f].u; out->base[f] = faces[f].base; out->c[f] = faces[f].c;
+        out->m0[f] = faces[f].w == 0 ? ~0u : 0u; out->m1[f] = faces[f].w == 1 ? ~0u : 0u; out->m2[f] = faces[f].w == 2 ? ~0u : 0u;
+    }
+    for (size_t f = faces.size(); f < (size_t)LAT_MAX_FACES; ++f) { out->w[f] = 2; out->m2[f] = ~0u; out->c[f] = std::numeric_limits<float>::quiet_NaN(); }   // (see IcpLattice::m0)
+    out->nface = (int)faces.size();
+}
 
 static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz, size_t stride, int m) {
     std::vector<float> raw((size_t)m * 3);
@@ -1644,6 +1780,7 @@ static std::shared_ptr<const PreparedTemplate> prepare_template(const void* xyz,
         P->big_ok = ok && covered == m;
         if (!P->big_ok) su.n = 0;
     }
+    lattice_detect(raw.data(), m, &P->lat);
     P->xyz.swap(raw);
     std::lock_guard<std::mutex> lk(mu);
     if (cache.size() >= 16) cache.erase(cache.begin());
@@ -1672,6 +1809,8 @@ static int upload_template(cd_context* c, int slot, int off, const PreparedTempl
     c->tpl_gridded[slot] = grid.ncell > 0;
     c->tpl_big[slot] = P.big_ok;
     HIPCHK(c, copy_sync(c, c->d_super + slot, &P.super, sizeof(IcpSuper), hipMemcpyHostToDevice));
+    HIPCHK(c, copy_sync(c, c->d_lat + slot, &P.lat, sizeof(IcpLattice), hipMemcpyHostToDevice));
+    c->tpl_faces[slot] = P.lat.nface;
     return CD_OK;
 }
 
@@ -1705,6 +1844,42 @@ int cd_set_template(cd_context* c, int slot, const void* xyz, size_t stride, int
         off += c->tpl_prep[k]->m_pad;
     }
     c->tpl_used = off;
+    return CD_OK;
+}
+
+int cd_template_lattice_faces(const cd_context* c, int slot) {
+    if (!c || slot < 0 || slot >= CD_MAX_TEMPLATES) return CD_ERR_INVALID_ARG;
+    if (c->tpl_m[slot] <= 0) return CD_ERR_NO_TEMPLATE;
+    return c->tpl_faces[slot];
+}
+
+int cd_lattice_detect(const void* xyz, size_t stride, int m, int32_t* out) {
+    if (!xyz || m <= 0 || stride < 12) return CD_ERR_INVALID_ARG;
+    std::vector<float> raw((size_t)m * 3);
+    for (int i = 0; i < m; ++i) std::memcpy(&raw[3 * (size_t)i], (const char*)xyz + (size_t)i * stride, 12);
+    auto L = std::make_unique<IcpLattice>();
+    lattice_detect(raw.data(), m, L.get());
+    for (int f = 0; out && f < L->nface; ++f) {
+        const int w = L->w[f], u = L->fast[f], v = 3 - w - u;
+        const int32_t row[5] = {w, u, L->base[f], L->n[u], L->n[v]};
+        std::memcpy(out + 5 * f, row, sizeof(row));
+    }
+    return L->nface;
+}
+
+int cd_template_nearest(cd_context* c, int slot, const void* queries, size_t stride, int n, int32_t* out_index, float* out_d2) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    if (slot < 0 || slot >= CD_MAX_TEMPLATES || !queries || n <= 0 || stride < 12 || !out_index || !out_d2) return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    if (c->tpl_m[slot] <= 0) return fail(c, CD_ERR_NO_TEMPLATE, "template slot empty");
+    if (c->tpl_faces[slot] <= 0) return fail(c, CD_ERR_INVALID_ARG, "the slot's template is not a lattice: its nearest-neighbour searches only exist inside the ICP kernels");
+    if ((long long)n > (long long)c->N * c->F) return fail(c, CD_ERR_CAPACITY, "more queries than the context holds points");
+    hipSetDevice(c->device);
+    invalidate_last(c);
+    int st = upload_points(c, queries, stride, n, c->d_src0);
+    if (st) return st;
+    LAUNCH(c, launch_lat_nn(c->stream, c->d_lat + slot, c->d_src0, n, c->d_nn, c->d_d2));
+    HIPCHK(c, copy_sync(c, out_index, c->d_nn, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost));
+    HIPCHK(c, copy_sync(c, out_d2, c->d_d2, sizeof(float) * (size_t)n, hipMemcpyDeviceToHost));
     return CD_OK;
 }
 
