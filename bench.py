@@ -307,6 +307,8 @@ def main():
     tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
     prm = capi.default_params()
     prm.rgb_offset = 12
+    if os.environ.get("CUBOID_BENCH_ICP_ITERS"):      # experiment only (how fast is the chain WITHOUT its ICP iterations?): the line is marked
+        prm.icp_max_iterations = int(os.environ["CUBOID_BENCH_ICP_ITERS"])
     tpl_by_slot = {0: tpl}
     if args.config == 5:
         from perception_amd import synth
@@ -704,8 +706,11 @@ def main():
                                  "frac_of_157.3_TFLOPs": fl / (head_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS})
                 except (OSError, KeyError, ValueError):
                     pass
+        if os.environ.get("CUBOID_BENCH_ICP_ITERS"):
+            print("bench.py: CUBOID_BENCH_ICP_ITERS is set - an EXPERIMENT with the ICP cut short, not the metric", file=sys.stderr)
         out = {
-            "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)",
+            "metric": "frames/sec (640x480 D435 cloud, plane+cluster+ICP)" if not os.environ.get("CUBOID_BENCH_ICP_ITERS") else
+                      "EXPERIMENT (ICP capped at %s iterations): NOT the metric" % os.environ["CUBOID_BENCH_ICP_ITERS"],
             "value": value, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -131,7 +131,7 @@ struct IcpSuper {
 // and verified bit by bit against the uploaded points by cd_set_template (lattice_detect, cuboid_hip.hip); the nearest
 // neighbour of a query is then a closed form over the axis tables (k_icp_lat.hip) - no search structure, no template image.
 constexpr int LAT_MAX_FACES = 6;           // (a cuboid has six)
-constexpr int LAT_MAX_TAB = 736;           // axis table entries of one template, the three axes together
+constexpr int LAT_MAX_TAB = 512;           // axis table entries of one template, the three axes together
 struct IcpLattice {
     int32_t nface;                 // 0: not a lattice - the generic searches of k_icp.hip take the template
     int32_t ntab;                  // entries of tab in use

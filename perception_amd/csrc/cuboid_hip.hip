@@ -91,7 +91,7 @@ struct cd_context {
     IcpLattice* d_lat = nullptr;                                  // per template slot: axis tables and faces of a lattice template (nface = 0: none)
     int tpl_faces[CD_MAX_TEMPLATES] = {0};                        // faces of the slot's lattice (0: the generic searches take it)
     int icp_lattice = 1;                                          // CUBOID_ICP_LATTICE=0: lattice templates take the generic searches too (A/B, fallback tests)
-    int lat_threads = 0;                                          // CUBOID_LAT_THREADS: workgroup size of k_icp_lat (256 / 512 / 1024; 0 = by the launch's shape)
+    int lat_shape[3] = {0, 0, 0};                                 // CUBOID_LAT_SHAPE=cpw,wpc[,per_slot]: clusters per workgroup, waves per cluster, clusters per slot of k_icp_lat (0: by regime)
     hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
                                                                   // first (stream2); with icp_lowprio both are low-priority streams, so that CUs that come free go to the
                                                                   // short front-end kernels of the other batches in flight before the next persistent workgroup
@@ -691,23 +691,28 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     };
     HIPCHK(c, hipEventRecord(c->ev[5], c->stream));
     if (n_lat > 0) {
-        // one workgroup per cluster, largest first.  Workgroup size: four waves per cluster when the launch has clusters enough to
-        // fill the chip that way (a wave of a big batch then owns ~5 passes of 64 points per iteration and the per-iteration
-        // costs that do not shrink - two barriers, the fold of the moment sums, the single-lane solve - are paid by few waves),
-        // sixteen when there are few clusters or very large ones (latency: one frame; config 5's thousands of points)
+        // the clusters of the launch, largest first
         int no = 0;
         for (int k = 0; k < ncl; ++k) if (in_lat[(size_t)k]) c->h_order[no++] = k;
         std::stable_sort(c->h_order, c->h_order + no, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
-        int threads = c->lat_threads;
-        if (threads <= 0) {
-            threads = n_lat >= 384 ? 256 : (n_lat >= 96 ? 512 : 1024);
-            if (lat_max_n > 16384) threads = 1024;
-            else if (lat_max_n > 4096) threads = std::max(threads, 512);
-        }
-        LAUNCH(c, launch_icp_lat(c->stream, n_lat, threads, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, ip));
+        // Shape of the launch (k_icp_lat.hip): clusters per workgroup x waves per cluster.  A call that has the GPU to itself wants
+        // the launch short: one cluster per workgroup, four waves each when there are clusters enough to fill the chip that way,
+        // eight or sixteen for few or very large clusters (one frame; config 5's thousands of points).  With other batches in
+        // flight the chip is full anyway: four clusters per workgroup, two waves each, pay the single-lane solve of a round once
+        // for the four (measured on config 3, seven in flight, profiles/r05_lat_shapes.txt: 1x4 145-146 k, 4x2 149-151 k, 8x2 146 k,
+        // 4x4 139 k, 4x1 131 k frames/s; alone 1x4 1.34 ms, 1x8 1.30, 4x2 2.2, 4x1 2.8).  CUBOID_LAT_SHAPE=cpw,wpc[,clusters per slot].
+        const bool busy = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 3;
+        int cpw = 1, wpc = n_lat >= 384 ? 4 : (n_lat >= 96 ? 8 : 16), per_slot = 1;
+        if (lat_max_n > 16384) wpc = 16;
+        else if (lat_max_n > 4096) wpc = std::max(wpc, 8);
+        if (busy && n_lat >= 256 && lat_max_n <= 8192) { cpw = 4; wpc = 2; }
+        if (c->lat_shape[0] > 0) { cpw = c->lat_shape[0]; wpc = std::max(1, c->lat_shape[1]); per_slot = std::max(1, c->lat_shape[2]); }
+        const int n_wg = std::max(1, (n_lat + cpw * per_slot - 1) / (cpw * per_slot));
+        HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
+        LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, ip));
         c->timing.icp_kernel_launches = 1;
-        c->timing.icp_regime = (1 << 16) | std::min(n_lat, 0xffff);
+        c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         if (n_lat == n_live) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
@@ -1431,7 +1436,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_DONATE")) c->icp_donate = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_ICP_LATTICE")) c->icp_lattice = std::atoi(m);
-    if (const char* m = std::getenv("CUBOID_LAT_THREADS")) c->lat_threads = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_LAT_SHAPE")) std::sscanf(m, "%d,%d,%d", &c->lat_shape[0], &c->lat_shape[1], &c->lat_shape[2]);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;

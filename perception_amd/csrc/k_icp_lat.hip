@@ -27,10 +27,7 @@
 // ~100 vector instructions per query with no divergence, against ~2400 per 64-query pass of the pruned searches, and no
 // 116 KB template image: a workgroup needs <= 12 KB of LDS, so ICP workgroups stop monopolising CUs.
 //
-// Launch shape: ONE workgroup per cluster, all iterations and the fitness pass inside it (as k_icp_cluster): per iteration
-// every wave takes passes of 64 points (X <- T X in place, search, 16 fixed-point moment sums of rule C4 kept in registers),
-// the sums meet in LDS, thread 0 runs Umeyama + SVD + the convergence tests (icp_solve.hpp, same code as k_icp_solve), two
-// barriers.  The hardware's workgroup dispatcher does the load balancing the persistent kernels did with queues and hand-overs.
+// Launch shape: a workgroup keeps one or several clusters going, every cluster's whole ICP inside it (k_icp_lat<CPW, WPC> below).
 // No MFMA: there is no dense contraction here (3x3 matrices only).
 #include "kernels.hpp"
 #include "icp_solve.hpp"
@@ -188,9 +185,6 @@ __device__ __forceinline__ int lat_index(const int4* s_face, const LatFaces& F, 
     return fd.z + iv * s_face[LAT_MAX_FACES + h.face].z + iu;
 }
 
-// workgroups per CU the register allocation is held to: four waves per SIMD (128 registers: the single-lane solve is what needs them)
-#define LAT_WG_PER_CU(threads) ((threads) == 256 ? 4 : ((threads) == 512 ? 2 : 1))
-
 // one PCL iteration's state update from the moment sums (what k_icp_solve / pipe_solve do): TransformationEstimationSVD,
 // final_transformation_ = transformation_ * final_transformation_, DefaultConvergenceCriteria::hasConverged.  Returns done.
 __device__ __forceinline__ int lat_solve(IcpState* so, const unsigned long long* A, int n, const IcpParams& prm) {
@@ -222,118 +216,245 @@ __device__ __forceinline__ int lat_solve(IcpState* so, const unsigned long long*
     return done;
 }
 
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS, LAT_WG_PER_CU(THREADS)) k_icp_lat(const int* __restrict__ order, const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
-                                                     unsigned long long* __restrict__ accf, const IcpLattice* __restrict__ lats,
-                                                     float4* __restrict__ src, const float4* __restrict__ src0, IcpParams prm) {
-    __shared__ float4 s_tab[LAT_MAX_TAB];
-    __shared__ int4 s_face[2 * LAT_MAX_FACES];
-    __shared__ unsigned long long s_acc[16];
-    __shared__ IcpState s_so;
-    __shared__ int s_done;
+// ---------------------------------------------------------------------------------------------------------------------------
+// k_icp_lat<CPW, WPC>: a workgroup keeps CPW clusters ("slots") going, WPC waves each, and works in ROUNDS of two phases:
+//   work  : the waves of a slot take the passes (64 points each) of the slot's current step - a PCL iteration (X <- T X in
+//           place, nearest neighbours, the 16 fixed-point moment sums of rule C4 kept in registers and folded into the slot's
+//           LDS accumulators) or, once converged, the final transform + getFitnessScore() pass;            -- barrier --
+//   solve : lane s of wave 0 finishes slot s's step: Umeyama + SVD + convergence tests (lat_solve: the same code as
+//           k_icp_solve), or the write-back of a finished cluster and the refill of the slot from the launch's cluster queue.
+//           The solves of a workgroup's slots run SIDE BY SIDE in the lanes of one wave.                     -- barrier --
+// Why this shape (measured, tools/lat_threads_serial.sh): a step of a 1 400-point cluster is ~19 us of passes for one wave
+// and ~9.6 us of single-lane solve (3 300 dependent instructions: IEEE divisions and square roots of the Jacobi sweeps).
+// One cluster per workgroup of four waves spends two thirds of its life with three waves parked behind one lane; CPW
+// clusters per workgroup pay that solve once per round for all of them.  <1, 4> / <1, 16> (one cluster, many waves) remain the
+// latency shapes: a launch that has the GPU to itself, a single frame.
+// Each slot has its own copy of its template's tables (a launch may mix templates: BASELINE config 5), restaged when a refill
+// brings a cluster of another template.
+// ---------------------------------------------------------------------------------------------------------------------------
+#ifdef CD_LAT_TIMERS
+// phase times of k_icp_lat, summed over workgroups (thread 0's clock64 cycles): [0] work phase, [1] wait at the barrier after it,
+// [2] solve phase, [3] wait at the barrier after it, [4] rounds, [5] staging
+__device__ unsigned long long g_lat_stats[8];
+extern "C" int cd_debug_lat_stats(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lat_stats), sizeof(g_lat_stats)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[8] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lat_stats), z, sizeof(z)); }
+    return 0;
+}
+#define LAT_T(k) { const long long tn_ = clock64(); tph[k] += tn_ - tlast; tlast = tn_; }
+#else
+#define LAT_T(k)
+#endif
+
+struct LatSlot {
+    int k, src_off, n, tslot;   // the cluster (index, first point, points, template slot)
+    int phase;                  // LAT_ITER / LAT_FIT / LAT_EMPTY
+    int gen;                    // bumped by every refill: the slot's waves restage tables and face descriptors
+    int ready;                  // the work phase of this round added a step's sums
+    int pad;
+};
+enum { LAT_ITER = 0, LAT_FIT = 1, LAT_EMPTY = 2 };
+
+#ifndef CD_LAT_WAVES_PER_EU
+#define CD_LAT_WAVES_PER_EU 4   // four waves per SIMD: 128 registers - the single-lane solve is what needs them
+#endif
+template <int CPW, int WPC>
+__global__ void __launch_bounds__(CPW * WPC * WAVE, CD_LAT_WAVES_PER_EU)
+k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
+          unsigned long long* __restrict__ accf, const IcpLattice* __restrict__ lats, float4* __restrict__ src,
+          const float4* __restrict__ src0, int* __restrict__ queue, IcpParams prm) {
+    constexpr int THREADS = CPW * WPC * WAVE;
+    __shared__ float4 s_tab[CPW][LAT_MAX_TAB];
+    __shared__ int4 s_face[CPW][2 * LAT_MAX_FACES];
+    __shared__ unsigned long long s_acc[CPW][16];
+    __shared__ IcpState s_so[CPW];
+    __shared__ LatSlot s_slot[CPW];
+    __shared__ int s_flags[2];   // [0] every slot is empty, [1] some slot was refilled in this round
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int NW = THREADS / WAVE;
-    const int k = order[blockIdx.x];
-    const IcpCluster c = cl[k];
-    if (st[2 * (size_t)k].done) return;   // host pre-marked (too few points / no template); uniform
-    LatFaces F;
-    if (threadIdx.x < 16) s_acc[threadIdx.x] = 0ull;
-    if (threadIdx.x == 0) { s_so = st[2 * (size_t)k]; s_done = 0; }
-    lat_stage<THREADS>(lats + c.slot, F, s_tab, s_face);
-    const bool nf3 = F.nface <= 3;   // (uniform)
-    float4* pts = src + c.src_off;
-    const float4* pts0 = src0 + c.src_off;
-    const int n = c.n, npass = (n + 63) >> 6;
-    for (int it = 0;; ++it) {
-        float T[12];
-        if (it > 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i) T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so.T[i])));   // (uniform: scalar registers)
+    const int slot = wave / WPC, sub = wave % WPC;
+    // refill of slot s by one lane: the next live cluster of the queue (largest first), or nothing left
+    auto refill = [&](int s) {
+        LatSlot& sl = s_slot[s];
+        for (int i = 0; i < 16; ++i) s_acc[s][i] = 0ull;
+        sl.ready = 0;
+        for (;;) {
+            const int item = atomicAdd(queue, 1);
+            if (item >= nitems) { sl.phase = LAT_EMPTY; return; }
+            const int k = order[item];
+            if (st[2 * (size_t)k].done) continue;   // host pre-marked (too few points / no template)
+            const IcpCluster c = cl[k];
+            sl.k = k; sl.src_off = c.src_off; sl.n = c.n; sl.tslot = c.slot;
+            s_so[s] = st[2 * (size_t)k];
+            sl.phase = LAT_ITER;
+            sl.gen += 1;
+            return;
         }
-        unsigned long long S[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = 0ull;
-        for (int pss = wave; pss < npass; pss += NW) {
-            const int myq = (pss << 6) + lane;
-            const bool act = myq < n;
-            const float4 p = pts[act ? myq : n - 1];
-            float px = p.x, py = p.y, pz = p.z;
-            if (it > 0) {   // X <- T*X, written back by the lane that owns the point
-                xform(T, p.x, p.y, p.z, px, py, pz);
-                if (act) pts[myq] = make_float4(px, py, pz, p.w);
-            }
-            const LatHit h = (nf3 ? lat_nearest<true, 3>(s_tab, s_face, F, px, py, pz) : lat_nearest<true, LAT_MAX_FACES>(s_tab, s_face, F, px, py, pz));
-            // float -> fixed point (rule C4) in four instructions per term (fixq_fast, common.hpp), valid while every term stays
-            // below 2^50 / 2^shift; a wave with a lane outside that range takes the general conversion - same integers either way
-            const float pv[3] = {px, py, pz}, qv[3] = {h.nx, h.ny, h.nz};
-            const float big_c = fmaxf(fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fabsf(pv[2])), fmaxf(fmaxf(fabsf(qv[0]), fabsf(qv[1])), fabsf(qv[2])));
-            const bool fast = ballot64(act && !(big_c < 256.f && h.d < 16384.f)) == 0ull;
-            if (act) {
-                if (fast) {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        S[a] += fixq_fast(pv[a], FIX_SHIFT);
-                        S[3 + a] += fixq_fast(qv[a], FIX_SHIFT);
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += fixq_fast(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
-                    }
-                    S[15] += fixq_fast(h.d, FIX_SHIFT_D2);
-                } else {
-#pragma unroll
-                    for (int a = 0; a < 3; ++a) {
-                        S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
-                        S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
-#pragma unroll
-                        for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
-                    }
-                    S[15] += (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
+    };
+    if (threadIdx.x < CPW) { s_slot[threadIdx.x].gen = 0; refill(threadIdx.x); }
+    if (threadIdx.x == 0) { s_flags[0] = 0; s_flags[1] = 1; }
+    __syncthreads();
+    int my_gen = 0;
+#ifdef CD_LAT_TIMERS
+    long long tph[6] = {0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
+    for (;;) {
+        if (s_flags[1]) {   // (uniform) some slot has a new cluster: its waves stage the tables of the cluster's template
+            const LatSlot sl = s_slot[slot];
+            const bool mine = sl.phase != LAT_EMPTY && sl.gen != my_gen;
+            if (mine) {
+                const IcpLattice* __restrict__ L = lats + sl.tslot;
+                for (int i = sub * WAVE + lane; i < L->ntab; i += WPC * WAVE) s_tab[slot][i] = L->tab[i];
+                if (sub == 0 && lane < LAT_MAX_FACES) {
+                    const int f = lane, w = L->w[f], u = L->fast[f], v = 3 - w - u;
+                    s_face[slot][f] = make_int4(w, u, L->base[f], __float_as_int(L->c[f]));
+                    s_face[slot][LAT_MAX_FACES + f] = make_int4(L->toff[u], L->toff[v < 0 || v > 2 ? 0 : v], L->n[u], 0);
                 }
+                my_gen = sl.gen;
+            }
+            __syncthreads();
+        }
+        LAT_T(5)
+        // ---- work phase ----
+        {
+            // (the slot's words as scalars; the face words of its template are re-read every round - a few scalar loads that hit
+            // the constant cache - rather than carried across the solve phase in forty scalar registers)
+            const int phase = __builtin_amdgcn_readfirstlane(s_slot[slot].phase), n = __builtin_amdgcn_readfirstlane(s_slot[slot].n);
+            const int src_off = __builtin_amdgcn_readfirstlane(s_slot[slot].src_off), tslot = __builtin_amdgcn_readfirstlane(s_slot[slot].tslot);
+            const int npass = (n + 63) >> 6;
+            float4* pts = src + src_off;
+            const float4* tab = s_tab[slot];
+            const int4* face = s_face[slot];
+            LatFaces F;
+            {
+                const IcpLattice* __restrict__ L = lats + (phase == LAT_EMPTY ? 0 : tslot);
+                F.nface = L->nface;
+#pragma unroll
+                for (int f = 0; f < LAT_MAX_FACES; ++f) { F.m0[f] = L->m0[f]; F.m1[f] = L->m1[f]; F.m2[f] = L->m2[f]; F.c[f] = L->c[f]; }
+                F.nx = L->n[0]; F.ny = L->n[1]; F.nz = L->n[2]; F.tox = L->toff[0]; F.toy = L->toff[1]; F.toz = L->toff[2];
+                F.ox = L->o[0]; F.oy = L->o[1]; F.oz = L->o[2]; F.ivx = L->inv[0]; F.ivy = L->inv[1]; F.ivz = L->inv[2];
+            }
+            const bool nf3 = F.nface <= 3;
+            if (phase == LAT_ITER) {
+                const bool moved = s_so[slot].iters > 0;   // X <- T*X from the second iteration on
+                float T[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so[slot].T[i])));   // (uniform: scalar registers)
+                unsigned long long S[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[i] = 0ull;
+                // (the points of the next pass are requested before the current pass is worked on: one wave per SIMD per cluster has
+                // nothing else to cover an L2 round trip with)
+                float4 pnext = pts[min((sub << 6) + lane, n - 1)];
+                for (int pss = sub; pss < npass; pss += WPC) {
+                    const int myq = (pss << 6) + lane;
+                    const bool act = myq < n;
+                    const float4 p = pnext;
+                    pnext = pts[min(((pss + WPC) << 6) + lane, n - 1)];
+                    float px = p.x, py = p.y, pz = p.z;
+                    if (moved) {   // written back by the lane that owns the point
+                        xform(T, p.x, p.y, p.z, px, py, pz);
+                        if (act) pts[myq] = make_float4(px, py, pz, p.w);
+                    }
+                    const LatHit h = nf3 ? lat_nearest<true, 3>(tab, face, F, px, py, pz) : lat_nearest<true, LAT_MAX_FACES>(tab, face, F, px, py, pz);
+                    // float -> fixed point (rule C4) in four instructions per term (fixq_fast, common.hpp), valid while every term stays
+                    // below 2^50 / 2^shift; a wave with a lane outside that range takes the general conversion - same integers either way
+                    const float pv[3] = {px, py, pz}, qv[3] = {h.nx, h.ny, h.nz};
+                    const float big_c = fmaxf(fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fabsf(pv[2])), fmaxf(fmaxf(fabsf(qv[0]), fabsf(qv[1])), fabsf(qv[2])));
+                    const bool fast = ballot64(act && !(big_c < 256.f && h.d < 16384.f)) == 0ull;
+                    if (act) {
+                        if (fast) {
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                S[a] += fixq_fast(pv[a], FIX_SHIFT);
+                                S[3 + a] += fixq_fast(qv[a], FIX_SHIFT);
+#pragma unroll
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += fixq_fast(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                            }
+                            S[15] += fixq_fast(h.d, FIX_SHIFT_D2);
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
+                                S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
+#pragma unroll
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
+                            }
+                            S[15] += (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
+                        }
+                    }
+                }
+                if (sub < npass) wave_fold_to_lds(S, 16, s_acc[slot]);
+                if (sub == 0 && lane == 0) s_slot[slot].ready = 1;
+            } else if (phase == LAT_FIT) {
+                // final X <- T*X (PCL transforms before it tests convergence), then getFitnessScore() of Tfinal * original source
+                const float4* pts0 = src0 + src_off;
+                float T[12], Tf[12];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) {
+                    T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so[slot].T[i])));
+                    Tf[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so[slot].Tfinal[i])));
+                }
+                unsigned long long S[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) S[i] = 0ull;
+                float4 pnext = pts[min((sub << 6) + lane, n - 1)], p0next = pts0[min((sub << 6) + lane, n - 1)];
+                for (int pss = sub; pss < npass; pss += WPC) {
+                    const int myq = (pss << 6) + lane;
+                    const bool act = myq < n;
+                    const float4 p = pnext, p0 = p0next;
+                    pnext = pts[min(((pss + WPC) << 6) + lane, n - 1)];
+                    p0next = pts0[min(((pss + WPC) << 6) + lane, n - 1)];
+                    float ox, oy, oz;
+                    xform(T, p.x, p.y, p.z, ox, oy, oz);
+                    if (act) pts[myq] = make_float4(ox, oy, oz, p.w);
+                    float qx, qy, qz;
+                    xform(Tf, p0.x, p0.y, p0.z, qx, qy, qz);
+                    const LatHit h = nf3 ? lat_nearest<false, 3>(tab, face, F, qx, qy, qz) : lat_nearest<false, LAT_MAX_FACES>(tab, face, F, qx, qy, qz);
+                    const bool fast = ballot64(act && !(h.d < 16384.f)) == 0ull;
+                    if (act) S[0] += fast ? fixq_fast(h.d, FIX_SHIFT_D2) : (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
+                }
+                if (sub < npass) wave_fold_to_lds(S, 1, s_acc[slot]);
             }
         }
-        if (wave < npass) wave_fold_to_lds(S, 16, s_acc);
+        LAT_T(0)
         __syncthreads();
+        LAT_T(1)
+        // ---- solve phase: lane s of wave 0 <-> slot s (everything below happens in wave 0, whose LDS operations execute in
+        // program order: the flag is cleared before a refill raises it, and thread 0 sees the other lanes' phases) ----
+        if (threadIdx.x == 0) s_flags[1] = 0;
+        if (threadIdx.x < CPW) {
+            const int s = threadIdx.x;
+            LatSlot& sl = s_slot[s];
+            if (sl.phase == LAT_ITER && sl.ready) {
+                if (lat_solve(&s_so[s], s_acc[s], sl.n, prm)) sl.phase = LAT_FIT;
+                for (int i = 0; i < 16; ++i) s_acc[s][i] = 0ull;
+                sl.ready = 0;
+            } else if (sl.phase == LAT_FIT) {
+                s_so[s].done = 1;
+                s_so[s].converged = 1;
+                st[2 * (size_t)sl.k] = s_so[s];
+                st[2 * (size_t)sl.k + 1] = s_so[s];
+                accf[sl.k] = s_acc[s][0];
+                refill(s);
+                if (sl.phase != LAT_EMPTY) s_flags[1] = 1;
+            }
+        }
         if (threadIdx.x == 0) {
-            s_done = lat_solve(&s_so, s_acc, n, prm);
-            for (int i = 0; i < 16; ++i) s_acc[i] = 0ull;
+            int all_empty = 1;
+            for (int s = 0; s < CPW; ++s) all_empty &= s_slot[s].phase == LAT_EMPTY ? 1 : 0;
+            s_flags[0] = all_empty;
         }
+        LAT_T(2)
         __syncthreads();
-        if (s_done) break;
+        LAT_T(3)
+#ifdef CD_LAT_TIMERS
+        tph[4] += 1;
+#endif
+        if (s_flags[0]) break;
     }
-    // final X <- T*X (PCL transforms before it tests convergence), then getFitnessScore() of Tfinal * original source
-    {
-        float T[12], Tf[12];
-#pragma unroll
-        for (int i = 0; i < 12; ++i) {
-            T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so.T[i])));
-            Tf[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so.Tfinal[i])));
-        }
-        unsigned long long S[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) S[i] = 0ull;
-        for (int pss = wave; pss < npass; pss += NW) {
-            const int myq = (pss << 6) + lane;
-            const bool act = myq < n;
-            const float4 p = pts[act ? myq : n - 1];
-            float ox, oy, oz;
-            xform(T, p.x, p.y, p.z, ox, oy, oz);
-            if (act) pts[myq] = make_float4(ox, oy, oz, p.w);
-            const float4 p0 = pts0[act ? myq : n - 1];
-            float qx, qy, qz;
-            xform(Tf, p0.x, p0.y, p0.z, qx, qy, qz);
-            const LatHit h = (nf3 ? lat_nearest<false, 3>(s_tab, s_face, F, qx, qy, qz) : lat_nearest<false, LAT_MAX_FACES>(s_tab, s_face, F, qx, qy, qz));
-            const bool fast = ballot64(act && !(h.d < 16384.f)) == 0ull;
-            if (act) S[0] += fast ? fixq_fast(h.d, FIX_SHIFT_D2) : (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
-        }
-        if (wave < npass) wave_fold_to_lds(S, 1, s_acc);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            s_so.done = 1;
-            s_so.converged = 1;
-            st[2 * (size_t)k] = s_so;
-            st[2 * (size_t)k + 1] = s_so;
-            accf[k] = s_acc[0];
-        }
-    }
+#ifdef CD_LAT_TIMERS
+    if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_lat_stats[i], (unsigned long long)tph[i]);
+#endif
 }
 
 // diagnostic / test entry: nearest template point of arbitrary queries (original index and canonical d2)
@@ -352,12 +473,22 @@ __global__ void __launch_bounds__(BLOCK) k_lat_nn(const IcpLattice* __restrict__
     }
 }
 
-void launch_icp_lat(hipStream_t s, int nitems, int threads, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
-                    const IcpLattice* lats, float4* src, const float4* src0, IcpParams prm) {
-    if (nitems <= 0) return;
-    if (threads >= 1024) hipLaunchKernelGGL(k_icp_lat<1024>, dim3(nitems), dim3(1024), 0, s, order, cl, st, accf, lats, src, src0, prm);
-    else if (threads >= 512) hipLaunchKernelGGL(k_icp_lat<512>, dim3(nitems), dim3(512), 0, s, order, cl, st, accf, lats, src, src0, prm);
-    else hipLaunchKernelGGL(k_icp_lat<256>, dim3(nitems), dim3(256), 0, s, order, cl, st, accf, lats, src, src0, prm);
+// shape = clusters per workgroup * 256 + waves per cluster (1 | 2 | 4 | 8 x 1 | 2 | 4 | 8 | 16, at most 16 waves per workgroup)
+template <int CPW, int WPC>
+static void launch_lat_shape(hipStream_t s, int nitems, int n_wg, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
+                             const IcpLattice* lats, float4* src, const float4* src0, int* queue, IcpParams prm) {
+    hipLaunchKernelGGL((k_icp_lat<CPW, WPC>), dim3(n_wg), dim3(CPW * WPC * WAVE), 0, s, nitems, order, cl, st, accf, lats, src, src0, queue, prm);
+}
+void launch_icp_lat(hipStream_t s, int nitems, int cpw, int wpc, int n_wg, const int* order, const IcpCluster* cl, IcpState* st,
+                    unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, IcpParams prm) {
+    if (nitems <= 0 || n_wg <= 0) return;
+#define CD_LAT_CASE(C, W) if (cpw == C && wpc == W) return launch_lat_shape<C, W>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, prm);
+    CD_LAT_CASE(1, 1) CD_LAT_CASE(1, 2) CD_LAT_CASE(1, 4) CD_LAT_CASE(1, 8) CD_LAT_CASE(1, 16)
+    CD_LAT_CASE(2, 1) CD_LAT_CASE(2, 2) CD_LAT_CASE(2, 4)
+    CD_LAT_CASE(4, 1) CD_LAT_CASE(4, 2) CD_LAT_CASE(4, 4)
+    CD_LAT_CASE(8, 1) CD_LAT_CASE(8, 2)
+#undef CD_LAT_CASE
+    launch_lat_shape<1, 4>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, prm);
 }
 void launch_lat_nn(hipStream_t s, const IcpLattice* lat, const float4* q, int n, int* out_idx, float* out_d2) {
     if (n <= 0) return;

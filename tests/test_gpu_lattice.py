@@ -7,7 +7,7 @@ template_cuboid_L200_W100_H75.pcd - is a union of axis-aligned lattices; cd_set_
    lowest original index): index and distance bits, near / far / mid-cell / +-300 m along a face normal (a tie walk across a
    whole face);
  * the ICP on lattice templates against the oracle and, byte for byte, against the generic searches (CUBOID_ICP_LATTICE=0),
-   for every workgroup size of k_icp_lat, single clusters and batches, one template and several, lattice and arbitrary
+   for the launch shapes of k_icp_lat (clusters per workgroup x waves per cluster, slots refilled from the queue), single clusters and batches, one template and several, lattice and arbitrary
    templates mixed in one batch."""
 import os
 
@@ -121,13 +121,13 @@ def _icp_cases(template):
             ("beyond the fast fixed-point range", (sub[:700] + F32([0, 400.0, 0])).astype(F32))]
 
 
-@pytest.mark.parametrize("threads", ["", "256", "512", "1024"])
-def test_lattice_icp_equals_the_oracle_and_the_generic_search(O, template, threads, monkeypatch):
+@pytest.mark.parametrize("shape", ["", "1,1", "1,4", "2,2", "4,1", "8,2"])
+def test_lattice_icp_equals_the_oracle_and_the_generic_search(O, template, shape, monkeypatch):
     """cd_icp on one cluster: iterations, transform bits, fitness and the aligned cloud equal the oracle's and the generic
-    search's, for every workgroup size of k_icp_lat; 6-face template included."""
+    search's, for launch shapes of k_icp_lat (clusters per workgroup, waves per cluster); 6-face template included."""
     big = pcd.read_xyz(os.path.join(GOLDEN, "template_cuboid_L200_W100_H75.pcd")).astype(F32)
-    if threads:
-        monkeypatch.setenv("CUBOID_LAT_THREADS", threads)
+    if shape:
+        monkeypatch.setenv("CUBOID_LAT_SHAPE", shape)
     got = {}
     for lattice in ("1", "0"):
         monkeypatch.setenv("CUBOID_ICP_LATTICE", lattice)
@@ -157,12 +157,13 @@ def test_lattice_icp_equals_the_oracle_and_the_generic_search(O, template, threa
             assert v[:5] == w[:5] and np.array_equal(v[5].view(np.uint32), w[5].view(np.uint32)), (slot, name)
 
 
-@pytest.mark.parametrize("threads", ["", "256", "1024"])
-def test_lattice_batch_equals_generic_batch_and_reports_its_search(O, template, threads, monkeypatch):
+@pytest.mark.parametrize("shape", ["", "1,4", "1,16", "4,1", "4,1,3", "8,1,2", "2,4,50"])
+def test_lattice_batch_equals_generic_batch_and_reports_its_search(O, template, shape, monkeypatch):
     """A batch through the fused call: records byte-identical with the lattice search and without, cd_timing says which ran,
-    one ICP launch; a sample of the frames against the oracle."""
-    if threads:
-        monkeypatch.setenv("CUBOID_LAT_THREADS", threads)
+    one ICP launch; a sample of the frames against the oracle.  Shapes: clusters per workgroup, waves per cluster, clusters
+    per slot (> 1: slots are refilled from the queue; 50: ONE workgroup works through the whole batch)."""
+    if shape:
+        monkeypatch.setenv("CUBOID_LAT_SHAPE", shape)
     idx = list(range(100, 124))
     frames = np.stack([synth.frame(i) for i in idx], 0)
     prm = capi.default_params()
@@ -191,10 +192,14 @@ def test_lattice_batch_equals_generic_batch_and_reports_its_search(O, template, 
     assert np.array_equal(rec["1"], rec["0"])
 
 
-def test_lattice_and_arbitrary_templates_in_one_batch(O, template, monkeypatch):
+@pytest.mark.parametrize("shape", ["", "4,1,2", "2,2,7"])
+def test_lattice_and_arbitrary_templates_in_one_batch(O, template, shape, monkeypatch):
     """template_slot = -1 (every cluster against every template, opd.cpp:376-413): two lattice templates and one scanned object in
-    one batch - the lattice clusters go to k_icp_lat, the others to the generic drivers; best-fitness records byte-identical
-    to the all-generic run, cd_timing.icp_search = 2."""
+    one batch - the lattice clusters go to k_icp_lat (slots of one workgroup hold clusters of different templates, and a refill
+    brings a slot a cluster of another template: its tables are restaged), the others to the generic drivers; best-fitness
+    records byte-identical to the all-generic run, cd_timing.icp_search = 2."""
+    if shape:
+        monkeypatch.setenv("CUBOID_LAT_SHAPE", shape)
     obj = pcd.read_xyz(os.path.join(GOLDEN, "eraser_ascii_tf.pcd")).astype(F32)
     small = templates.template_xyz32(0.2, 0.075, 0.1, 0.005)
     idx = list(range(30, 38))
