@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define CD_ABI_VERSION 3
+#define CD_ABI_VERSION 4
 #define CD_MAX_TEMPLATES 8          /* template slots per context (BASELINE config 5 uses 5) */
 #define CD_MAX_CLUSTERS_PER_FRAME 8 /* cluster slots in the fixed-size per-frame record; a frame with more clusters still
                                      * gets an ICP for every one of them (opd.cpp:376): see cd_get_cluster_results       */
@@ -198,6 +198,16 @@ int cd_crop_voxel(cd_context* ctx, const void* points, size_t stride_bytes, int 
                   const cd_params* prm, float* out_xyz, uint32_t* out_rgb, int capacity,
                   int* out_n_cropped, int* out_n_voxels);
 
+/* One PassThrough filter as a call of its own: pcl::PassThrough<PCLPointCloud2>::filter (gps.cpp:53-58 "z", :61-65 "x";
+ * opd.cpp:273-289, :331-336).  field = 0 / 1 / 2 for setFilterFieldName("x" / "y" / "z"), -1 for none (only non-finite points
+ * go).  A record is kept iff x, y, z and the field are finite and !(v > limit_max || v < limit_min), v compared as double
+ * (negative != 0, setFilterLimitsNegative: kept iff !(v < limit_max && v > limit_min)); kept records are copied whole
+ * (stride_bytes each, a multiple of 4, >= 12) in their input order.  The fused calls (cd_crop_voxel, cd_ground_plane,
+ * cd_process_*) apply the two crops of the launch files inside their first kernel; this entry is for a PassThrough that
+ * stands alone. */
+int cd_passthrough(cd_context* ctx, const void* points, size_t stride_bytes, int n, int field, double limit_min,
+                   double limit_max, int negative, void* out_points, int capacity, int* out_n);
+
 /* S2: seg.segment(*inliers, *coefficients) (gps.cpp:93).  inliers ascending. */
 int cd_segment_plane(cd_context* ctx, const void* xyz, size_t stride_bytes, int n,
                      const cd_params* prm, float coeff[4], int32_t* inliers, int capacity,
@@ -341,6 +351,10 @@ typedef struct cd_timing {
                                                    * arbitrary template, 1 the closed form for a template that is a union of axis-aligned
                                                    * lattices (every make_cuboid.py template; cd_template_lattice_faces), 2 both (mixed batch).
                                                    * Results do not depend on it                                                            */
+    int32_t icp_handover_lost;                    /* a cluster in hand-over between two workgroups was claimed and never arrived, or a waiting
+                                                   * workgroup ran out of polls: the call has FAILED with CD_ERR_DEVICE (its records are not
+                                                   * complete).  Cannot happen in a healthy launch; 0 otherwise                              */
+    int32_t reserved;
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

@@ -9,7 +9,7 @@ import os
 
 import numpy as np
 
-CD_ABI_VERSION = 3
+CD_ABI_VERSION = 4
 CD_MAX_TEMPLATES = 8
 CD_MAX_CLUSTERS_PER_FRAME = 8
 CD_FRAME_MORE_CLUSTERS = 1
@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "cd_set_template", "cd_crop_voxel", "cd_segment_plane", "cd_extract", "cd_surface_frame", "cd_bbox_filter", "cd_cluster", "cd_icp",
     "cd_process_batch", "cd_process_frame", "cd_process_batch_device", "cd_get_cluster_results", "cd_pose_to_position_quaternion",
     "cd_bbox_corners", "cd_get_timing", "cd_get_frame_cloud", "cd_get_cluster_points", "cd_ground_plane", "cd_set_frame_guesses",
-    "cd_template_lattice_faces", "cd_template_nearest", "cd_lattice_detect",
+    "cd_template_lattice_faces", "cd_template_nearest", "cd_lattice_detect", "cd_passthrough",
 ]
 
 CD_CLOUD_VOXELS, CD_CLOUD_OBJECTS = 0, 1
@@ -96,6 +96,7 @@ class CdTiming(C.Structure):
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
         ("scan_retries", C.c_int32), ("icp_regime", C.c_int32),
         ("icp_handovers", C.c_int32), ("icp_search", C.c_int32),
+        ("icp_handover_lost", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -182,6 +183,7 @@ def load_library(path=None):
     lib.cd_template_lattice_faces.argtypes = [vp, C.c_int]
     lib.cd_template_nearest.argtypes = [vp, C.c_int, vp, C.c_size_t, C.c_int, vp, vp]
     lib.cd_lattice_detect.argtypes = [vp, C.c_size_t, C.c_int, vp]
+    lib.cd_passthrough.argtypes = [vp, vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, vp, C.c_int, ip]
     if path is None:
         _lib = lib
     return lib
@@ -393,6 +395,17 @@ class Context:
             return
         g = np.ascontiguousarray(guesses, np.float32).reshape(-1, 16)
         self._check(self.lib.cd_set_frame_guesses(self.h, g.ctypes.data_as(C.POINTER(C.c_float)), g.shape[0]))
+
+    def passthrough(self, records, field, lo, hi, negative=False):
+        """pcl::PassThrough on whole records: `records` (n, k >= 3) of 4-byte items; field 'x' / 'y' / 'z' or None."""
+        r = np.ascontiguousarray(records)
+        assert r.ndim == 2 and r.dtype.itemsize == 4 and r.shape[1] >= 3
+        out = np.empty_like(r)
+        cnt = C.c_int()
+        f = -1 if field is None else "xyz".index(field)
+        self._check(self.lib.cd_passthrough(self.h, _ptr(r), r.shape[1] * 4, r.shape[0], f, float(lo), float(hi), 1 if negative else 0,
+                                            _ptr(out), r.shape[0], C.byref(cnt)))
+        return out[:cnt.value].copy()
 
     def template_lattice_faces(self, slot):
         """Faces of the slot's template as a union of axis-aligned lattices (make_cuboid.py's output); 0 = an arbitrary cloud."""

@@ -25,7 +25,7 @@ static void print16(const char* tag, const float* T) {
 int main(int argc, char** argv) {
     std::string frame_path, tpl_path, mode = "opd";
     double voxel_size = 0.005, distance_threshold = 0.015, icp_fitness_score = 0.0004;   // launch values
-    bool invert = true;
+    bool invert = true, unfused = false;   // --unfused 1: look at the cropped cloud, so that the three filters run one by one
     for (int i = 1; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--frame") frame_path = v;
@@ -34,6 +34,7 @@ int main(int argc, char** argv) {
         else if (k == "--voxel_size") voxel_size = std::atof(v.c_str());
         else if (k == "--distance_threshold") distance_threshold = std::atof(v.c_str());
         else if (k == "--icp_fitness_score") icp_fitness_score = std::atof(v.c_str());
+        else if (k == "--unfused") unfused = std::atoi(v.c_str()) != 0;
     }
     if (frame_path.empty() || tpl_path.empty()) { std::fprintf(stderr, "usage: cuboid_driver --frame f.bin --template t.pcd [--mode gps|opd]\n"); return 2; }
     // "message" -> cloud (pcl_conversions::toPCL / fromROSMsg)
@@ -50,15 +51,29 @@ int main(int argc, char** argv) {
         Device::instance((int)cloud->points.size(), 1, 0);
     } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return 3; }
 
-    // gps.cpp:53-73  crop z, crop x, voxel grid
+    // gps.cpp:53-58  filter the points in z
+    PointCloud<PointXYZRGB>::Ptr cloud_filtered_ptr_z(new PointCloud<PointXYZRGB>);
+    PointCloud<PointXYZRGB>::Ptr cloud_filtered_ptr(new PointCloud<PointXYZRGB>);
+    PassThrough<PointXYZRGB> pass_z;
+    pass_z.setInputCloud(cloud);
+    pass_z.setFilterFieldName("z");
+    pass_z.setFilterLimits(0.0, 0.9);
+    pass_z.filter(*cloud_filtered_ptr_z);
+    // gps.cpp:61-65  filter the points in x
+    PassThrough<PointXYZRGB> pass;
+    pass.setInputCloud(cloud_filtered_ptr_z);
+    pass.setFilterFieldName("x");
+    pass.setFilterLimits(-0.2, 0.2);
+    pass.filter(*cloud_filtered_ptr);
+    if (unfused) std::printf("cropped %zu\n", cloud_filtered_ptr->size());   // (looking at the cloud runs the two filters one by one)
+    // gps.cpp:69-73  downsample
     PointCloud<PointXYZRGB>::Ptr voxel_ptr(new PointCloud<PointXYZRGB>);
-    CropVoxelGrid<PointXYZRGB> downsample;
-    downsample.setInputCloud(cloud);
-    downsample.setFilterLimitsZ(0.0, 0.9);
-    downsample.setFilterLimitsX(-0.2, 0.2);
+    VoxelGrid<PointXYZRGB> downsample;
+    downsample.setInputCloud(cloud_filtered_ptr);
     downsample.setLeafSize((float)voxel_size, (float)voxel_size, (float)voxel_size);
     if (!downsample.filter(*voxel_ptr)) return 4;
     std::printf("voxels %zu\n", voxel_ptr->size());
+    std::fprintf(stderr, "crops fused into the voxel call: %d\n", downsample.lastFilterWasFused() ? 1 : 0);
 
     // gps.cpp:76-93  plane segmentation
     ModelCoefficients::Ptr coefficients(new ModelCoefficients);

@@ -18,6 +18,11 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
@@ -37,13 +42,17 @@ struct Barrier {   // (std::barrier is C++20; the rest of the host code is C++17
     std::mutex mu;
     std::condition_variable cv;
     int n, waiting = 0, phase = 0;
+    bool broken = false;    // a rank failed: nobody waits any more
     explicit Barrier(int n_) : n(n_) {}
-    void wait() {
+    bool wait() {           // false: the barrier was broken (before or while waiting)
         std::unique_lock<std::mutex> lk(mu);
+        if (broken) return false;
         const int ph = phase;
         if (++waiting == n) { waiting = 0; ++phase; cv.notify_all(); }
-        else cv.wait(lk, [&] { return phase != ph; });
+        else cv.wait(lk, [&] { return phase != ph || broken; });
+        return !broken;
     }
+    void abort() { { std::lock_guard<std::mutex> lk(mu); broken = true; } cv.notify_all(); }
 };
 
 void shard_range(int n_frames, int rank, int world, int* lo, int* hi) {
@@ -63,13 +72,14 @@ struct Shared {
     std::vector<std::vector<cd_frame_result>> gathered;   // per rank: F records
     std::vector<std::vector<cd_frame_result>> local;      // per rank: its slice (host gather)
     std::vector<double> step_s;
+    std::vector<double> hbm_used_gb;      // per rank: device memory in use on its device after the last step (hipMemGetInfo)
     std::atomic<int> failed{0};
     std::string err[64];
 };
 
 #define RANK_CHECK(cond, msg)                                                                       \
     do {                                                                                            \
-        if (!(cond)) { sh->err[g] = std::string(msg); sh->failed.store(1); goto done; }             \
+        if (!(cond)) { sh->err[g] = std::string(msg); sh->failed.store(1); bar->abort(); goto done; } \
     } while (0)
 
 void rank_main(Shared* sh, Barrier* bar, int g) {
@@ -97,7 +107,8 @@ void rank_main(Shared* sh, Barrier* bar, int g) {
                        "hipMemcpy(frames) failed");
     }
     for (int s = 0; s < sh->warmup + sh->steps; ++s) {
-        if (s == sh->warmup) { (void)hipDeviceSynchronize(); bar->wait(); }
+        if (sh->failed.load()) goto done;          // another rank failed: leave at the step boundary
+        if (s == sh->warmup) { (void)hipDeviceSynchronize(); if (!bar->wait()) goto done; }
         const auto t0 = std::chrono::steady_clock::now();
         std::memset(res.data(), 0, rec * res.size());
         if (nloc > 0)
@@ -109,16 +120,20 @@ void rank_main(Shared* sh, Barrier* bar, int g) {
             RANK_CHECK(hipStreamSynchronize(stream) == hipSuccess, "stream sync failed");
         } else {              // one-GPU rehearsal: the slices meet in host memory
             sh->local[g] = res;
-            bar->wait();
+            if (!bar->wait()) goto done;
             for (int r = 0; r < sh->G; ++r) std::memcpy(all.data() + (size_t)r * per_max, sh->local[r].data(), rec * per_max);
-            bar->wait();
+            if (!bar->wait()) goto done;
         }
         if (s >= sh->warmup) {
             (void)hipDeviceSynchronize();
             sh->step_s[g] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     }
-    bar->wait();
+    {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) sh->hbm_used_gb[g] = (double)(tot - fr) / 1e9;
+    }
+    if (!bar->wait()) goto done;
     sh->gathered[g].resize((size_t)sh->F);
     for (int r = 0; r < sh->G; ++r) {   // drop the padding: frame order
         int rlo, rhi;
@@ -126,10 +141,12 @@ void rank_main(Shared* sh, Barrier* bar, int g) {
         if (rhi > rlo) std::memcpy(sh->gathered[g].data() + rlo, all.data() + (size_t)r * per_max, rec * (size_t)(rhi - rlo));
     }
 done:
+    // A failed rank (or one that saw another fail) must not leave the others inside a collective: the barrier is broken (nobody
+    // waits at it any more), every rank leaves at its next step boundary, and an RCCL communicator is aborted so that a
+    // collective already entered by the others returns.  main() reports and exits with 5.
     if (sh->failed.load()) {
-        // a failed rank must not leave the others waiting at a barrier or inside the collective: the process ends
-        std::fprintf(stderr, "rank %d: %s\n", g, sh->err[g].c_str());
-        std::_Exit(5);
+        if (!sh->err[g].empty()) std::fprintf(stderr, "rank %d: %s\n", g, sh->err[g].c_str());
+        if (sh->use_rccl && sh->comms[g]) { (void)ncclCommAbort(sh->comms[g]); sh->comms[g] = nullptr; }
     }
     if (d_frames) (void)hipFree(d_frames);
     if (d_send) (void)hipFree(d_send);
@@ -181,20 +198,18 @@ int main(int argc, char** argv) {
     for (int a = 0; a < sh.G && sh.use_rccl; ++a)
         for (int b = a + 1; b < sh.G; ++b)
             if (sh.devices[a] == sh.devices[b]) { std::fprintf(stderr, "two ranks on device %d: RCCL needs one device per rank (use --gather host)\n", sh.devices[a]); return 2; }
-    // frames
-    std::vector<char> frames;
+    // frames: mapped, not read (BASELINE config 4 is 2048 frames = 10 GB; every rank uploads its slice straight from the mapping)
     {
-        FILE* f = std::fopen(frames_path.c_str(), "rb");
-        if (!f) { std::perror("frames"); return 2; }
-        std::fseek(f, 0, SEEK_END);
-        const long bytes = std::ftell(f);
-        std::fseek(f, 0, SEEK_SET);
-        if (bytes <= 0 || bytes % ((long)sh.N * 16) != 0) { std::fprintf(stderr, "%s is not a whole number of %d-point frames\n", frames_path.c_str(), sh.N); return 2; }
-        frames.resize((size_t)bytes);
-        if (std::fread(frames.data(), 1, (size_t)bytes, f) != (size_t)bytes) { std::fprintf(stderr, "short read\n"); return 2; }
-        std::fclose(f);
-        sh.F = (int)(bytes / ((long)sh.N * 16));
-        sh.frames = frames.data();
+        const int fd = open(frames_path.c_str(), O_RDONLY);
+        struct stat stt;
+        if (fd < 0 || fstat(fd, &stt) != 0) { std::perror("frames"); return 2; }
+        const long long bytes = (long long)stt.st_size;
+        if (bytes <= 0 || bytes % ((long long)sh.N * 16) != 0) { std::fprintf(stderr, "%s is not a whole number of %d-point frames\n", frames_path.c_str(), sh.N); return 2; }
+        void* m = mmap(nullptr, (size_t)bytes, PROT_READ, MAP_PRIVATE, fd, 0);
+        close(fd);
+        if (m == MAP_FAILED) { std::perror("mmap(frames)"); return 2; }
+        sh.F = (int)(bytes / ((long long)sh.N * 16));
+        sh.frames = (const char*)m;
     }
     // template (iterative_closest_point.cpp:159)
     {
@@ -210,11 +225,13 @@ int main(int argc, char** argv) {
     sh.gathered.resize((size_t)sh.G);
     sh.local.resize((size_t)sh.G);
     sh.step_s.assign((size_t)sh.G, 0.0);
+    sh.hbm_used_gb.assign((size_t)sh.G, 0.0);
     Barrier bar(sh.G);
     std::vector<std::thread> th;
     for (int g = 0; g < sh.G; ++g) th.emplace_back(rank_main, &sh, &bar, g);
     for (auto& t : th) t.join();
-    if (sh.use_rccl) for (auto c : sh.comms) ncclCommDestroy(c);
+    if (sh.failed.load()) { std::fprintf(stderr, "cuboid_multi_gpu: a rank failed\n"); return 5; }
+    if (sh.use_rccl) for (auto c : sh.comms) if (c) ncclCommDestroy(c);
     int differ = 0;
     for (int g = 1; g < sh.G; ++g)
         if (std::memcmp(sh.gathered[g].data(), sh.gathered[0].data(), sizeof(cd_frame_result) * (size_t)sh.F) != 0) ++differ;
@@ -224,11 +241,13 @@ int main(int argc, char** argv) {
         std::fwrite(sh.gathered[0].data(), sizeof(cd_frame_result), (size_t)sh.F, f);
         std::fclose(f);
     }
-    double t = 0.0;
+    double t = 0.0, hbm = 0.0;
     for (double s : sh.step_s) t = s > t ? s : t;
+    for (double v : sh.hbm_used_gb) hbm = v > hbm ? v : hbm;
+    // (with --gather host the step time of a rank includes two host barriers: a rehearsal figure, not the RCCL path's)
     std::printf("{\"driver\": \"cuboid_multi_gpu\", \"n_gpus\": %d, \"gather\": \"%s\", \"frames\": %d, \"steps\": %d, \"warmup\": %d, "
-                "\"ms_per_step\": %.4f, \"frames_per_s\": %.1f, \"record_bytes\": %zu, \"ranks_identical\": %s}\n",
+                "\"ms_per_step\": %.4f, \"frames_per_s\": %.1f, \"record_bytes\": %zu, \"ranks_identical\": %s, \"hbm_used_gb_max\": %.2f}\n",
                 sh.G, sh.use_rccl ? "rccl" : "host", sh.F, sh.steps, sh.warmup, 1e3 * t / sh.steps, sh.F * sh.steps / (t > 0 ? t : 1e-9),
-                sizeof(cd_frame_result), differ ? "false" : "true");
+                sizeof(cd_frame_result), differ ? "false" : "true", hbm);
     return differ ? 6 : 0;
 }

@@ -14,6 +14,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <stdexcept>
@@ -36,16 +37,67 @@ struct alignas(16) PointXYZRGB {
 };
 static_assert(sizeof(PointXYZ) == 16 && sizeof(PointXYZRGB) == 32, "PCL point layouts");
 
+namespace detail {
+// `points` of a PointCloud: a std::vector<PointT> whose content may still be owed.  PassThrough::filter leaves its output
+// DEFERRED - the filter runs (on the device, cd_passthrough) the first time somebody looks at the points - so that the
+// reference's sequence PassThrough("z") -> PassThrough("x") -> VoxelGrid (gps.cpp:53-73, opd.cpp:273-298), whose two
+// intermediate clouds nobody ever looks at, becomes ONE fused device call (VoxelGrid::filter below recognises the chain).
+// Every accessor forces the content first, so code written against pcl::PointCloud<T>::points reads the same.
+template <class PointT>
+class LazyPoints {
+public:
+    using value_type = PointT;
+    using iterator = typename std::vector<PointT>::iterator;
+    using const_iterator = typename std::vector<PointT>::const_iterator;
+    size_t size() const { force(); return v_.size(); }
+    bool empty() const { force(); return v_.empty(); }
+    PointT* data() { force(); return v_.data(); }
+    const PointT* data() const { force(); return v_.data(); }
+    PointT& operator[](size_t i) { force(); return v_[i]; }
+    const PointT& operator[](size_t i) const { force(); return v_[i]; }
+    PointT& back() { force(); return v_.back(); }
+    const PointT& back() const { force(); return v_.back(); }
+    iterator begin() { force(); return v_.begin(); }
+    iterator end() { force(); return v_.end(); }
+    const_iterator begin() const { force(); return v_.begin(); }
+    const_iterator end() const { force(); return v_.end(); }
+    void push_back(const PointT& p) { force(); v_.push_back(p); }
+    void resize(size_t n) { force(); v_.resize(n); }
+    void reserve(size_t n) { force(); v_.reserve(n); }
+    void clear() { pending_ = nullptr; v_.clear(); }
+    template <class It> void assign(It a, It b) { pending_ = nullptr; v_.assign(a, b); }
+    std::vector<PointT>& vector() { force(); return v_; }
+    const std::vector<PointT>& vector() const { force(); return v_; }
+    operator const std::vector<PointT>&() const { return vector(); }
+    // the content is owed: `make` fills the vector at the first access
+    void defer(std::function<void(std::vector<PointT>&)> make) { v_.clear(); pending_ = std::move(make); }
+    bool deferred() const { return (bool)pending_; }
+private:
+    void force() const {
+        if (!pending_) return;
+        auto f = std::move(pending_);
+        pending_ = nullptr;
+        f(v_);
+    }
+    mutable std::vector<PointT> v_;
+    mutable std::function<void(std::vector<PointT>&)> pending_;
+};
+struct Crop { int field; double lo, hi; bool negative; };   // one PassThrough: field 0 / 1 / 2 = "x" / "y" / "z", -1 = none
+}  // namespace detail
+
 template <class PointT>
 struct PointCloud {
     using Ptr = std::shared_ptr<PointCloud<PointT>>;
     using ConstPtr = std::shared_ptr<const PointCloud<PointT>>;
-    std::vector<PointT> points;
-    uint32_t width = 0, height = 1;
+    detail::LazyPoints<PointT> points;
+    uint32_t width = 0, height = 1;   // (of a deferred cloud: set when its points are first looked at - use size())
     bool is_dense = true;
     size_t size() const { return points.size(); }
     void push_back(const PointT& p) { points.push_back(p); width = (uint32_t)points.size(); height = 1; }
-    void clear() { points.clear(); width = 0; height = 1; }
+    void clear() { points.clear(); width = 0; height = 1; crop_root.reset(); crops.clear(); }
+    // provenance of a deferred PassThrough output: this cloud == `crops` applied in order to *crop_root (kept alive here)
+    ConstPtr crop_root;
+    std::vector<detail::Crop> crops;
 };
 struct PointIndices {
     using Ptr = std::shared_ptr<PointIndices>;
@@ -73,24 +125,91 @@ private:
     cd_context* ctx_ = nullptr;
 };
 
-// gps.cpp:53-73 / opd.cpp:273-298: PassThrough("z") + PassThrough("x") + VoxelGrid in one device pass.
+// gps.cpp:53-65 / opd.cpp:273-289, :331-336: pcl::PassThrough.  filter() leaves the output DEFERRED (LazyPoints above): a
+// PassThrough whose output only ever feeds the next filter costs nothing by itself; one that is looked at runs cd_passthrough.
 template <class PointT>
-class CropVoxelGrid {
+class PassThrough {
 public:
     void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { in_ = c; }
-    void setFilterLimitsZ(double lo, double hi) { prm_.crop_z_min = lo; prm_.crop_z_max = hi; }   // pass_z.setFilterLimits
-    void setFilterLimitsX(double lo, double hi) { prm_.crop_x_min = lo; prm_.crop_x_max = hi; }   // pass.setFilterLimits
-    void setLeafSize(float lx, float, float) { prm_.leaf_size = lx; }                              // downsample.setLeafSize
-    // returns false (and an empty cloud) on "Leaf size is too small"
+    void setFilterFieldName(const std::string& name) {
+        field_ = name == "x" ? 0 : (name == "y" ? 1 : (name == "z" ? 2 : -2));
+        if (name.empty()) field_ = -1;
+        if (field_ == -2) throw std::invalid_argument("PassThrough: only the fields x, y, z");
+    }
+    std::string getFilterFieldName() const { return field_ < 0 ? std::string() : std::string(1, "xyz"[field_]); }
+    void setFilterLimits(double lo, double hi) { lo_ = lo; hi_ = hi; }
+    void setFilterLimitsNegative(bool n) { neg_ = n; }
+    void filter(PointCloud<PointT>& out) {
+        out.clear();
+        if (!in_) return;
+        // the chain continues when the input is itself a PassThrough output nobody has looked at; otherwise it starts here
+        if (in_->crop_root && in_->points.deferred()) { out.crop_root = in_->crop_root; out.crops = in_->crops; }
+        else out.crop_root = in_;
+        out.crops.push_back(detail::Crop{field_, lo_, hi_, neg_});
+        const typename PointCloud<PointT>::ConstPtr root = out.crop_root;
+        const std::vector<detail::Crop> crops = out.crops;
+        PointCloud<PointT>* self = &out;
+        out.points.defer([root, crops, self](std::vector<PointT>& v) {
+            v.assign(root->points.begin(), root->points.end());
+            for (const detail::Crop& cr : crops) {
+                if (v.empty()) break;
+                std::vector<PointT> kept(v.size());
+                int n = 0;
+                const int st = cd_passthrough(Device::instance().ctx(), v.data(), sizeof(PointT), (int)v.size(), cr.field, cr.lo, cr.hi, cr.negative ? 1 : 0,
+                                              kept.data(), (int)kept.size(), &n);
+                if (st != CD_OK) { std::fprintf(stderr, "[pclhip::PassThrough] %s\n", cd_last_error(Device::instance().ctx())); n = 0; }
+                kept.resize((size_t)n);
+                v.swap(kept);
+            }
+            self->width = (uint32_t)v.size();
+            self->height = 1;
+        });
+    }
+private:
+    typename PointCloud<PointT>::ConstPtr in_;
+    int field_ = -1;
+    double lo_ = -std::numeric_limits<float>::max(), hi_ = std::numeric_limits<float>::max();   // PCL's defaults: FLT_MIN .. FLT_MAX as "no limit"
+    bool neg_ = false;
+};
+
+// gps.cpp:69-73 / opd.cpp:293-298: pcl::VoxelGrid.  When the input is the deferred output of PassThrough filters on "x" / "z"
+// (the reference's sequence), the crops and the voxel grid run as ONE device call on the chain's root cloud (cd_crop_voxel:
+// the same points in the same order reach the grid, so the result is the one the three filters give one after the other).
+template <class PointT>
+class VoxelGrid {
+public:
+    void setInputCloud(const typename PointCloud<PointT>::ConstPtr& c) { in_ = c; }
+    void setLeafSize(float lx, float ly, float lz) {
+        if (lx != ly || lx != lz) throw std::invalid_argument("VoxelGrid: cubic leaves only (the reference sets one voxel_size, gps.cpp:72)");
+        prm_.leaf_size = lx;
+    }
+    // returns false (and an empty cloud) on "Leaf size is too small" (PCL warns and returns the input; the nodes stop here)
     bool filter(PointCloud<PointT>& out) {
         out.clear();
-        if (!in_ || in_->points.empty()) return true;
-        const int n = (int)in_->points.size();
+        if (!in_) return true;
+        const double inf = std::numeric_limits<double>::max();
+        prm_.crop_z_min = prm_.crop_x_min = -inf;
+        prm_.crop_z_max = prm_.crop_x_max = inf;
+        typename PointCloud<PointT>::ConstPtr src = in_;
+        if (in_->crop_root && in_->points.deferred()) {
+            bool fusable = true;
+            for (const detail::Crop& cr : in_->crops) fusable = fusable && !cr.negative && (cr.field == 0 || cr.field == 2 || cr.field == -1);
+            if (fusable) {
+                for (const detail::Crop& cr : in_->crops) {   // (two crops on one field: the intersection)
+                    if (cr.field == 2) { prm_.crop_z_min = std::max(prm_.crop_z_min, cr.lo); prm_.crop_z_max = std::min(prm_.crop_z_max, cr.hi); }
+                    if (cr.field == 0) { prm_.crop_x_min = std::max(prm_.crop_x_min, cr.lo); prm_.crop_x_max = std::min(prm_.crop_x_max, cr.hi); }
+                }
+                src = in_->crop_root;
+                fused_ = true;
+            }
+        }
+        if (src->points.empty()) return true;
+        const int n = (int)src->points.size();
         std::vector<float> xyz((size_t)n * 3);
         std::vector<uint32_t> rgb((size_t)n);
         prm_.rgb_offset = sizeof(PointT) >= 32 ? 16 : -1;
         int nc = 0, nv = 0;
-        const int st = cd_crop_voxel(Device::instance().ctx(), in_->points.data(), sizeof(PointT), n, &prm_, xyz.data(), rgb.data(), n, &nc, &nv);
+        const int st = cd_crop_voxel(Device::instance().ctx(), src->points.data(), sizeof(PointT), n, &prm_, xyz.data(), rgb.data(), n, &nc, &nv);
         if (st != CD_OK) { std::fprintf(stderr, "[pclhip::VoxelGrid] %s\n", cd_last_error(Device::instance().ctx())); return false; }
         out.points.resize((size_t)nv);
         for (int i = 0; i < nv; ++i) {
@@ -102,9 +221,11 @@ public:
         out.width = (uint32_t)nv;
         return true;
     }
+    bool lastFilterWasFused() const { return fused_; }   // (diagnostic: the crops ran inside the voxel call)
 private:
     cd_params prm_ = defaults();
     typename PointCloud<PointT>::ConstPtr in_;
+    bool fused_ = false;
     static cd_params defaults() { cd_params p; cd_default_params(&p); return p; }
 };
 

@@ -168,12 +168,15 @@ struct IcpParams {
     int32_t pipe_slots;    // k_icp_pipe / k_icp_pipe_big: clusters a workgroup keeps in flight (1 .. CD_PIPE_SLOTS; scheduling only)
     int32_t donate;        // 1: workgroups that run out of clusters wait and take over running ones (scheduling only; `don` valid)
     int32_t* don;          // hand-over control block, zeroed before the launch: DON_* words, then DON_CAP mailbox entries
+    int32_t don_idle;      // tests: workgroups 0 .. don_idle-1 never take from the queue - everything they run reaches them by hand-over
+    int32_t don_fault;     // tests: 1 = the first donor claims a mailbox entry and never publishes it (the loss path must be REPORTED)
 };
 // k_icp_pipe's hand-over of RUNNING clusters (IcpParams::donate): words of the control block
 constexpr int DON_AVAIL = 0;      // workgroups waiting for a cluster minus clusters promised to them
 constexpr int DON_FINISHED = 1;   // clusters of the launch that are done (or were never started: pre-marked)
 constexpr int DON_TAIL = 2;       // mailbox entries written (or being written)
 constexpr int DON_HEAD = 3;       // mailbox entries taken
+constexpr int DON_ERR = 4;        // a waiter gave up on an entry it had claimed, or ran out of polls with clusters still open: the host fails the call
 constexpr int DON_BOX = 16;       // first mailbox entry: cluster id + 1 (0 = not written yet)
 constexpr int DON_CAP = 2048;     // entries (a launch hands over a few hundred clusters at most; beyond the cap nothing is handed over)
 

@@ -66,6 +66,7 @@ struct cd_context {
     float* d_d2 = nullptr;                                        // its squared distance
     int* d_queue = nullptr;                                       // ICP work queue heads (one per template group)
     int* d_don = nullptr;                                         // k_icp_pipe: hand-over control block + mailbox (common.hpp DON_*)
+    int don_idle = 0, don_fault = 0;                              // CUBOID_ICP_DON_IDLE / CUBOID_ICP_DON_FAULT: tests of the hand-over path (IcpParams::don_idle / don_fault)
     int icp_donate = -1;                                          // CUBOID_ICP_DONATE: -1 auto (a call alone on the device), 0 never, 1 always
     int* d_wgtab = nullptr;                                       // k_icp_pipe: {first item, end item, queue} per workgroup
     int* h_wgtab = nullptr;                                       // its pinned staging copy (3 * 1024 ints)
@@ -684,6 +685,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     ip.pipe_slots = c->icp_slots > 0 ? std::min(c->icp_slots, CD_PIPE_SLOTS) : (crowded ? CD_PIPE_SLOTS : std::min(2, CD_PIPE_SLOTS));
     ip.donate = 0;   // (set below for a whole-cluster launch that has the GPU to itself)
     ip.don = c->d_don;
+    ip.don_idle = c->don_idle;
+    ip.don_fault = c->don_fault;
     auto pipe_grid = [&](int n_items, int cap) {   // workgroups of a whole-cluster launch over n_items clusters
         if (c->icp_cpw > 0) return std::min((n_items + c->icp_cpw - 1) / c->icp_cpw, cap);
         if (!crowded || n_items <= cap) return std::min(n_items, cap);
@@ -841,10 +844,6 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         hipStream_t si = c->icp_lowprio >= 2 ? c->stream3 : c->stream;
-        if (si != c->stream) {
-            HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
-            HIPCHK(c, hipStreamWaitEvent(si, c->ev2[0], 0));
-        }
         if (pipe_ok || big_ok) {
             c->timing.icp_regime = (ip.pipe_slots << 16) | pipe_grid(ncl, wg_cap);
             // A launch that has the GPU to itself lets workgroups that run out of clusters wait and take over running ones
@@ -854,6 +853,10 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             const bool alone = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() <= 1;
             ip.donate = (c->icp_donate < 0 ? (alone && ncl > pipe_grid(ncl, wg_cap)) : c->icp_donate != 0) ? 1 : 0;
             if (ip.donate) HIPCHK(c, hipMemsetAsync(c->d_don, 0, sizeof(int) * (size_t)(DON_BOX + DON_CAP), c->stream));
+        }
+        if (si != c->stream) {   // (after the control block was zeroed on c->stream: the launch on `si` must see it zeroed - ADVICE r4)
+            HIPCHK(c, hipEventRecord(c->ev2[0], c->stream));
+            HIPCHK(c, hipStreamWaitEvent(si, c->ev2[0], 0));
         }
         if (pipe_ok)
             LAUNCH(c, launch_icp_pipe(si, ncl, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_tpl, c->d_tlok, c->d_thik, c->d_kdmap, c->d_grid, c->d_tcell, c->d_src, c->d_src0, c->d_nn,
@@ -872,14 +875,21 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         c->timing.icp_kernel_launches = 1;
         HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
-        if (ip.donate) HIPCHK(c, hipMemcpyAsync(c->h_ctl + 12, c->d_don, sizeof(int) * 4, hipMemcpyDeviceToHost, c->stream));
+        if (ip.donate) HIPCHK(c, hipMemcpyAsync(c->h_ctl + 8, c->d_don, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms1 = 0.f;
         hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
         c->timing.icp_kernel_ms = ms1;
         if (ip.donate) {
-            const int* w = c->h_ctl + 12;   // (copied with the records above)
+            const int* w = c->h_ctl + 8;   // (copied with the records above)
             c->timing.icp_handovers = w[DON_HEAD];
+            // every cluster of the launch was finished by somebody, and every mailbox entry that was written was taken
+            if (w[DON_ERR] != 0 || w[DON_FINISHED] != ncl || w[DON_HEAD] != std::min(w[DON_TAIL], DON_CAP)) {
+                c->timing.icp_handover_lost = 1;
+                std::snprintf(c->err, sizeof(c->err), "ICP hand-over lost a cluster: %d of %d clusters finished, %d entries published, %d taken, error word %d",
+                              w[DON_FINISHED], ncl, w[DON_TAIL], w[DON_HEAD], w[DON_ERR]);
+                return CD_ERR_DEVICE;
+            }
             if (std::getenv("CUBOID_DEBUG"))
                 std::fprintf(stderr, "cuboid_hip: hand-overs: %d published, %d taken, %d clusters finished of %d, waiting balance %d\n", w[DON_TAIL], w[DON_HEAD], w[DON_FINISHED], ncl, w[DON_AVAIL]);
         }
@@ -1435,6 +1445,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_CPW")) c->icp_cpw = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_SLOTS")) c->icp_slots = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_DONATE")) c->icp_donate = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_ICP_DON_IDLE")) c->don_idle = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_ICP_DON_FAULT")) c->don_fault = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_ICP_LATTICE")) c->icp_lattice = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_LAT_SHAPE")) std::sscanf(m, "%d,%d,%d", &c->lat_shape[0], &c->lat_shape[1], &c->lat_shape[2]);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
@@ -2127,6 +2139,40 @@ static int cd_extract_impl(cd_context* c, const void* points, size_t stride, int
     return CD_OK;
 }
 
+static int cd_passthrough_impl(cd_context* c, const void* points, size_t stride, int n, int field, double lo, double hi, int negative,
+                               void* out_points, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    hipSetDevice(c->device);
+    invalidate_last(c);
+    if ((!points && n > 0) || !out_n || n < 0 || capacity < 0 || stride < 12 || (stride & 3) || (!out_points && capacity > 0) || field < -1 || field > 2)
+        return fail(c, CD_ERR_INVALID_ARG, "bad arguments");
+    *out_n = 0;
+    if (n > c->N) return fail(c, CD_ERR_CAPACITY, "more points than the context capacity");
+    if (n == 0) return CD_OK;
+    const int words = (int)(stride / 4);
+    const size_t in_bytes = ((size_t)n * stride + 255) & ~(size_t)255;   // staging: the input records, then the records that are kept
+    int st = ensure_input(c, in_bytes + (size_t)n * stride);
+    if (st) return st;
+    HIPCHK(c, hipMemcpyAsync(c->d_in, points, (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
+    std::memset(&c->h_fs[0], 0, sizeof(FrameState));
+    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)c->T, c->stream));          // chained-scan state
+    HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
+    LAUNCH(c, launch_passthrough_mark(c->stream, c->d_in, stride, n, field < 0 ? -1 : 4 * field, lo, hi, negative ? 1 : 0, c->d_rank));
+    LAUNCH(c, launch_select_unmarked(c->stream, c->d_rank, n, c->d_tileA, c->d_fs, c->d_plane_idx, c->d_ticket));
+    st = sync_fs(c, 1);
+    if (st) return st;
+    const int kept = c->h_fs[0].n_plane;
+    if (kept > capacity) return fail(c, CD_ERR_CAPACITY, "output capacity too small");
+    if (kept > 0) {
+        char* d_out = (char*)c->d_in + in_bytes;
+        LAUNCH(c, launch_gather_records(c->stream, c->d_in, words, c->d_plane_idx, kept, d_out));
+        HIPCHK(c, copy_sync(c, out_points, d_out, (size_t)kept * stride, hipMemcpyDeviceToHost));
+    }
+    *out_n = kept;
+    return CD_OK;
+}
+
 static int cd_cluster_impl(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels,
                int32_t* sizes, int sizes_capacity, int* out_k) {
     if (!c) return CD_ERR_INVALID_ARG;
@@ -2354,6 +2400,10 @@ int cd_bbox_filter(cd_context* c, const void* xyz, size_t stride, int n, const d
 int cd_extract(cd_context* c, const void* points, size_t stride, int n, const int32_t* indices, int n_indices, int negative, void* out_points, int capacity, int* out_n) {
     if (!c) return CD_ERR_INVALID_ARG;
     return with_scan_retry(c, [&]() { return cd_extract_impl(c, points, stride, n, indices, n_indices, negative, out_points, capacity, out_n); });
+}
+int cd_passthrough(cd_context* c, const void* points, size_t stride, int n, int field, double limit_min, double limit_max, int negative, void* out_points, int capacity, int* out_n) {
+    if (!c) return CD_ERR_INVALID_ARG;
+    return with_scan_retry(c, [&] { return cd_passthrough_impl(c, points, stride, n, field, limit_min, limit_max, negative, out_points, capacity, out_n); });
 }
 int cd_cluster(cd_context* c, const void* xyz, size_t stride, int n, const cd_params* p, int32_t* labels, int32_t* sizes, int sizes_capacity, int* out_k) {
     if (!c) return CD_ERR_INVALID_ARG;

@@ -1419,8 +1419,9 @@ __device__ __noinline__ int pipe_solve(PipeSlot* sl, const IcpParams& prm) {
 // next cluster from the global queue into the slot (lane 0 of the finishing wave)
 // (items [gbeg, gend) of `order`: the clusters that share the workgroup's template)
 __device__ __forceinline__ void pipe_refill(PipeSlot* sl, int gbeg, int gend, const int* order, const IcpCluster* cl, const IcpState* st, int* queue,
-                                            int* don) {
+                                            int* don, bool no_queue = false) {
     sl->give = 0; sl->take = 0;
+    if (no_queue) { sl->phase = PH_EXHAUSTED; return; }   // (IcpParams::don_idle: this workgroup only ever works on hand-overs)
     for (;;) {
         const int item = gbeg + atomicAdd(queue, 1);
         if (item >= gend) { sl->phase = PH_EXHAUSTED; return; }
@@ -1492,14 +1493,15 @@ __device__ __forceinline__ int pipe_active_slots(const PipeSlot* slots) {
     return a;
 }
 // lane 0 of the finishing wave, cluster not converged: returns true when the slot's cluster went to the mailbox
-__device__ __noinline__ bool pipe_give(PipeSlot* sl, const PipeSlot* slots, IcpState* st, int* don) {
+__device__ __noinline__ bool pipe_give(PipeSlot* sl, const PipeSlot* slots, IcpState* st, int* don, bool fault) {
     bool gone = false;
     if (pipe_active_slots(slots) >= 2) {
         state_store_agent(&st[2 * (size_t)sl->k], sl->so);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the state is in memory before the entry says so
         const int t = __hip_atomic_fetch_add(don + DON_TAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t < DON_CAP) {
-            __hip_atomic_store(don + DON_BOX + t, sl->k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (!(fault && t == 0))   // (fault injection, tests: the first entry is claimed and never written)
+                __hip_atomic_store(don + DON_BOX + t, sl->k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             gone = true;
         }
     }
@@ -1508,7 +1510,11 @@ __device__ __noinline__ bool pipe_give(PipeSlot* sl, const PipeSlot* slots, IcpS
     return gone;
 }
 // thread 0 of a workgroup with nothing left: the id of a cluster to carry on with, or -1 when the launch is finished
-__device__ __noinline__ int pipe_wait_for_cluster(int* don, int total) {
+// Both bail-outs are REPORTED (DON_ERR; the host fails the call with CD_ERR_DEVICE): an entry that was claimed and never
+// appeared means its cluster left its donor and reached nobody; running out of polls with clusters still open means the
+// launch's bookkeeping is off.  Neither can happen in a healthy launch (a donor stores the entry right after claiming its
+// index; every running workgroup finishes its clusters on its own) - tests/test_gpu_timed_path.py injects the first.
+__device__ __noinline__ int pipe_wait_for_cluster(int* don, int total, int entry_spins) {
     __hip_atomic_fetch_add(don + DON_AVAIL, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int polls = 0; polls < (1 << 22); ++polls) {
         const int head = don_load(don + DON_HEAD), tail = min(don_load(don + DON_TAIL), DON_CAP);
@@ -1516,14 +1522,18 @@ __device__ __noinline__ int pipe_wait_for_cluster(int* don, int total) {
             int expect = head;
             if (__hip_atomic_compare_exchange_strong(don + DON_HEAD, &expect, head + 1, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
                 int v = 0;
-                for (int spins = 0; spins < (1 << 24) && v == 0; ++spins) v = don_load(don + DON_BOX + head);
-                return v - 1;   // (-1 only if the entry never appeared: its writer increments DON_TAIL and stores the entry back to back)
+                for (int spins = 0; spins < entry_spins && v == 0; ++spins) v = don_load(don + DON_BOX + head);
+                if (v == 0) __hip_atomic_store(don + DON_ERR, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // claimed, never published
+                return v - 1;
             }
             continue;
         }
         if (don_load(don + DON_FINISHED) >= total) return -1;
+        if (don_load(don + DON_ERR)) return -1;   // (somebody lost a cluster: FINISHED will never reach the total)
         __builtin_amdgcn_s_sleep(32);
     }
+    __hip_atomic_fetch_add(don + DON_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // this waiter is gone: no donor may promise it a cluster
+    __hip_atomic_store(don + DON_ERR, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return -1;
 }
 
@@ -1559,6 +1569,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
     int gbeg = 0, gend = ncl;
     if (wgtab) { gbeg = wgtab[3 * blockIdx.x]; gend = wgtab[3 * blockIdx.x + 1]; queue += wgtab[3 * blockIdx.x + 2]; }
     int* const don = (prm.donate && !wgtab) ? prm.don : nullptr;   // (hand-overs: launches with one queue only)
+    const bool no_queue = don && (int)blockIdx.x < prm.don_idle;   // (tests: this workgroup only ever gets work by hand-over)
     __shared__ int s_take;
     const IcpCluster c0 = cl[order[gbeg]];
     const IcpGrid g = grids[c0.slot];
@@ -1620,7 +1631,8 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
             sl->phase = sidx < prm.pipe_slots ? PH_FILL : PH_EXHAUSTED;   // (a slot the launch does not use is dropped at its first visit)
         }
         // slot 0 starts with a cluster; the other slots are filled at their first step (PH_FILL), after every workgroup took its first
-        pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue, don);
+        pipe_refill(&s_slot[0], gbeg, gend, order, cl, st, queue, don, no_queue);
+        if (no_queue) for (int sidx = 0; sidx < PIPE_SLOTS; ++sidx) s_slot[sidx].phase = PH_EXHAUSTED;
     }
     __syncthreads();
 #ifdef CD_TIMERS
@@ -1830,7 +1842,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                         } else {
                             sl->it += 1;
                             if (sl->give) {
-                                if (pipe_give(sl, s_slot, st, don)) { DON_DBG(24, don_t0); pipe_refill(sl, gbeg, gend, order, cl, st, queue, don); }
+                                if (pipe_give(sl, s_slot, st, don, prm.don_fault != 0)) { DON_DBG(24, don_t0); pipe_refill(sl, gbeg, gend, order, cl, st, queue, don, no_queue); }
                             } else if (waiting > 0 && pipe_active_slots(s_slot) >= 2) {
                                 // promise this cluster to one of the waiting workgroups; it goes after the next step
                                 if (__hip_atomic_fetch_add(don + DON_AVAIL, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > 0) sl->give = 1;
@@ -1846,7 +1858,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
                             accf[sl->k] = sl->acc[0];
                             if (don) __hip_atomic_fetch_add(don + DON_FINISHED, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         }
-                        pipe_refill(sl, gbeg, gend, order, cl, st, queue, don);
+                        pipe_refill(sl, gbeg, gend, order, cl, st, queue, don, no_queue);
                     }
                     for (int i = 0; i < 16; ++i) sl->acc[i] = 0ull;
                     sl->arrived = 0;
@@ -1868,7 +1880,7 @@ __device__ __forceinline__ void icp_pipe_body(int ncl, const int* __restrict__ o
 #ifdef CD_DONDBG
         const long long tw0 = wall_clock64();
 #endif
-        const int k = pipe_wait_for_cluster(don, gend - gbeg);
+        const int k = pipe_wait_for_cluster(don, gend - gbeg, prm.don_fault ? (1 << 14) : (1 << 24));
 #ifdef CD_DONDBG
         atomicAdd(&g_don_dbg[2], (unsigned long long)(wall_clock64() - tw0));
         if (k >= 0) DON_DBG(40, don_t0); else atomicMax(&g_don_dbg[1], (unsigned long long)(wall_clock64() - don_t0));

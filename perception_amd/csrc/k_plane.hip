@@ -299,6 +299,24 @@ __global__ void __launch_bounds__(BLOCK) k_mark_indices(const int* __restrict__ 
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < m) { const int k = idx[i]; if (k >= 0 && k < n) flag[k] = 1; }
 }
+// pcl::PassThrough<PCLPointCloud2> as a call of its own (cd_passthrough): flag[i] = 1 for the records it REMOVES - x, y or z
+// not finite, the field value not finite, or the value outside [lo, hi] compared as double (negative: inside (lo, hi)), exactly
+// PCL's `distance_value > filter_limit_max_ || distance_value < filter_limit_min_` (negative: `<` and `>`)
+__global__ void __launch_bounds__(BLOCK) k_passthrough_mark(const char* __restrict__ in, size_t stride, int n, int field_off, double lo, double hi,
+                                                            int negative, int* __restrict__ flag) {
+    const int i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const char* p = in + (size_t)i * stride;
+    const float x = *reinterpret_cast<const float*>(p), y = *reinterpret_cast<const float*>(p + 4), z = *reinterpret_cast<const float*>(p + 8);
+    bool remove = !((fabsf(x) <= 3.402823466e38f) && (fabsf(y) <= 3.402823466e38f) && (fabsf(z) <= 3.402823466e38f));
+    if (field_off >= 0) {
+        const float vf = *reinterpret_cast<const float*>(p + field_off);
+        const double v = (double)vf;
+        remove = remove || !(fabsf(vf) <= 3.402823466e38f);
+        remove = remove || (negative ? (v < hi && v > lo) : (v > hi || v < lo));
+    }
+    flag[i] = remove ? 1 : 0;
+}
 // positions i with flag[i] == 0, ascending (ordered compaction: ballots + chained scan over the tiles)
 __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict__ flag, int n, int* __restrict__ state,
                                                            FrameState* __restrict__ fs, int* __restrict__ out, int* __restrict__ ticket) {
@@ -362,6 +380,9 @@ __global__ void __launch_bounds__(BLOCK) k_pack_records(const float4* __restrict
 void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out) {
     const size_t tot = (size_t)m * words;
     if (tot > 0) hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, pts, m, words, rgb_word, pad3, (uint32_t*)out);
+}
+void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag) {
+    if (n > 0) hipLaunchKernelGGL(k_passthrough_mark, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, (const char*)in, stride, n, field_off, lo, hi, negative, flag);
 }
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag) {
     if (m > 0) hipLaunchKernelGGL(k_mark_indices, dim3((m + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, idx, m, n, flag);

@@ -22,6 +22,7 @@ void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint3
                                 int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
+void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag);
 void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out, int* ticket);
 void launch_gather_records(hipStream_t s, const void* in, int words, const int* idx, int m, void* out);
 void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out);

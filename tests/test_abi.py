@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     lib = capi.load_library()
     for name in _header_symbols():
         assert hasattr(lib, name), name
-    assert lib.cd_abi_version() == capi.CD_ABI_VERSION == 3
+    assert lib.cd_abi_version() == capi.CD_ABI_VERSION == 4
 
 
 def test_struct_layout_matches_header():

@@ -14,14 +14,17 @@ pytestmark = pytest.mark.gpu
 CPP = os.path.join(ROOT, "perception_amd", "cpp")
 
 
-def _run(mode, frame, tmp_path):
+def _run(mode, frame, tmp_path, unfused=False):
     subprocess.run(["make", "-C", CPP], check=True, stdout=subprocess.DEVNULL)
     fpath, tpath = str(tmp_path / "frame.bin"), str(tmp_path / "template.pcd")
     frame.astype(np.float32).tofile(fpath)
     open(tpath, "wb").write(templates.template_pcd_bytes(**templates.DEFAULT_TEMPLATE))
-    out = subprocess.run([os.path.join(CPP, "cuboid_driver"), "--frame", fpath, "--template", tpath, "--mode", mode],
-                         check=True, capture_output=True, text=True, timeout=120).stdout
-    return [ln.split() for ln in out.strip().splitlines()]
+    r = subprocess.run([os.path.join(CPP, "cuboid_driver"), "--frame", fpath, "--template", tpath, "--mode", mode, "--unfused", "1" if unfused else "0"],
+                       check=True, capture_output=True, text=True, timeout=120)
+    # the driver's body is gps.cpp:53-73 as written there - PassThrough("z"), PassThrough("x"), VoxelGrid: nobody looks at the two
+    # cropped clouds, so the crops run inside the voxel call; with --unfused it prints the cropped cloud's size first
+    assert ("crops fused into the voxel call: %d" % (0 if unfused else 1)) in r.stderr, r.stderr[-500:]
+    return [ln.split() for ln in r.stdout.strip().splitlines()]
 
 
 def _hexes(tokens):
@@ -68,3 +71,35 @@ def test_gps_plus_icp_callback_bodies(O, template, frames4, tmp_path):
     r = ro.clusters[0]
     assert (int(icp[2]), int(icp[4]), int(icp[6])) == (r.size, r.iterations, r.converged)
     assert _hexes(T[1:]) == [float(x) for x in r.T]
+
+
+def test_pcl_named_filters_one_by_one_equal_the_fused_call(O, frames4, tmp_path):
+    """pclhip::PassThrough x 2 + pclhip::VoxelGrid with PCL's names (gps.cpp:53-73).  Looked at one by one (every filter a
+    device call of its own: cd_passthrough, cd_passthrough, cd_crop_voxel without limits) they give exactly what the lazily
+    fused chain gives - same lines from the driver - and the cropped cloud has the oracle's N_c; cd_passthrough itself
+    against numpy on whole records (double limits, both signs of `negative`, non-finite points, every field)."""
+    fused = _run("opd", frames4[2], tmp_path)
+    unfused = _run("opd", frames4[2], tmp_path, unfused=True)
+    assert unfused[0][0] == "cropped" and unfused[1:] == fused
+    prm = capi.default_params()
+    st, vox, _, n_c, _ = O.crop_voxel(frames4[2], prm)
+    assert int(unfused[0][1]) == n_c
+    rec = frames4[2].copy()
+    rec[::97, 1] = np.nan
+    rec[5::131, 0] = np.inf
+    ctx = capi.Context(max_points=rec.shape[0], max_frames=1)
+    try:
+        xyz = rec[:, :3].astype(np.float64)
+        fin = np.isfinite(rec[:, :3]).all(1)
+        for field, lo, hi in (("z", 0.0, 0.9), ("x", -0.2, 0.2), ("y", -0.05, 0.1000000000001), (None, 0.0, 0.0)):
+            for neg in (False, True):
+                got = ctx.passthrough(rec.view(np.uint32), field, lo, hi, negative=neg)
+                if field is None:
+                    keep = fin
+                else:
+                    v = xyz[:, "xyz".index(field)]
+                    with np.errstate(invalid="ignore"):
+                        keep = fin & (~((v < hi) & (v > lo)) if neg else ~((v > hi) | (v < lo)))
+                assert np.array_equal(got, rec.view(np.uint32)[keep]), (field, neg)
+    finally:
+        ctx.close()

@@ -113,13 +113,17 @@ def test_pipe_slot_refill_with_capped_grid(O, template, max_wg, slots, monkeypat
         ctx.close()
 
 
+@pytest.mark.parametrize("lowprio", ["", "2"])
 @pytest.mark.parametrize("slots", ["2", "4"])
-def test_pipe_handover_of_running_clusters(O, template, slots, monkeypatch):
+def test_pipe_handover_of_running_clusters(O, template, slots, lowprio, monkeypatch):
     """A launch that has the GPU to itself lets workgroups that ran out of clusters take over RUNNING ones from workgroups
     that still have several (k_icp.hip, pipe_give / pipe_wait_for_cluster: the cluster's points and neighbour indices cross to
-    another CU, possibly another XCD, in the middle of its ICP).  31 clusters on 8 workgroups (measured: 4-11 hand-overs per
-    call): the hand-overs must happen
-    (cd_timing.icp_handovers), and the records must be the oracle's and byte-identical to a launch without hand-overs."""
+    another CU, possibly another XCD, in the middle of its ICP).  Deterministic, not a matter of timing: with
+    CUBOID_ICP_DON_IDLE=1 workgroup 0 never takes from the queue, so every cluster it runs reached it by hand-over, and with
+    31 clusters on 8 workgroups the other seven hold several clusters each for most of the launch - at least one hand-over
+    per call is certain (cd_timing.icp_handovers).  The records must be the oracle's and byte-identical to a launch without
+    hand-overs.  lowprio = 2: the launch goes to the context's side stream (the control block must be zeroed before that
+    stream is released - ADVICE r4)."""
     idx = list(range(60, 76))
     frames = np.stack([synth.frame(i) for i in idx], 0)
     prm = capi.default_params()
@@ -128,24 +132,59 @@ def test_pipe_handover_of_running_clusters(O, template, slots, monkeypatch):
     monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
     monkeypatch.setenv("CUBOID_ICP_MAX_WG", "8")
     monkeypatch.setenv("CUBOID_ICP_SLOTS", slots)
+    if lowprio:
+        monkeypatch.setenv("CUBOID_ICP_LOWPRIO", lowprio)
     got = {}
     for donate in ("1", "0"):
         monkeypatch.setenv("CUBOID_ICP_DONATE", donate)
+        monkeypatch.setenv("CUBOID_ICP_DON_IDLE", "1" if donate == "1" else "0")
         ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
         try:
             ctx.set_template(0, template)
-            handovers = 0
+            per_call = []
             for rep in range(3):                  # (the control block and the mailbox are reused from call to call)
                 res, _, _ = ctx.process_batch(frames, prm)
-                assert ctx.timing().icp_kernel_launches == 1
-                handovers += ctx.timing().icp_handovers
+                t = ctx.timing()
+                assert t.icp_kernel_launches == 1 and t.icp_handover_lost == 0
+                per_call.append(t.icp_handovers)
                 for f in range(len(frames)):
                     assert_record_matches_oracle(res[f], want[f], (donate, rep, idx[f]))
-            got[donate] = (capi.results_to_array(res).copy(), handovers)
+            got[donate] = (capi.results_to_array(res).copy(), per_call)
         finally:
             ctx.close()
-    assert got["0"][1] == 0 and got["1"][1] > 0, "no cluster changed workgroup: the test does not reach the hand-over path"
+    assert got["0"][1] == [0, 0, 0]
+    assert all(h >= 1 for h in got["1"][1]), "the idle workgroup can only have worked on hand-overs: %s" % got["1"][1]
     assert np.array_equal(got["0"][0], got["1"][0])
+
+
+def test_pipe_handover_that_loses_a_cluster_is_reported(template, monkeypatch):
+    """Fault injection (CUBOID_ICP_DON_FAULT=1): the first donor claims its mailbox entry and never publishes it, so the cluster
+    has left its workgroup and reaches nobody.  The taker gives up on the entry, raises the error word, every waiter leaves,
+    and the HOST fails the call with CD_ERR_DEVICE and cd_timing.icp_handover_lost = 1 - not a silent record with done = 0.
+    The context works again afterwards."""
+    idx = list(range(60, 76))
+    frames = np.stack([synth.frame(i) for i in idx], 0)
+    prm = capi.default_params()
+    monkeypatch.setenv("CUBOID_ICP_MODE", "pipe")
+    monkeypatch.setenv("CUBOID_ICP_MAX_WG", "8")
+    monkeypatch.setenv("CUBOID_ICP_DONATE", "1")
+    monkeypatch.setenv("CUBOID_ICP_DON_IDLE", "1")
+    monkeypatch.setenv("CUBOID_ICP_DON_FAULT", "1")
+    ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    monkeypatch.setenv("CUBOID_ICP_DON_FAULT", "0")
+    good = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
+    try:
+        ctx.set_template(0, template)
+        good.set_template(0, template)
+        with pytest.raises(capi.CuboidError) as e:
+            ctx.process_batch(frames, prm)
+        assert e.value.status == capi.CD_ERR_DEVICE and "hand-over lost a cluster" in str(e.value)
+        assert ctx.timing().icp_handover_lost == 1
+        res, _, _ = good.process_batch(frames, prm)          # the device is fine: a context without the fault gives the usual records
+        assert good.timing().icp_handover_lost == 0 and good.timing().icp_handovers >= 1
+    finally:
+        ctx.close()
+        good.close()
 
 
 def test_pipe_big_handover_of_running_clusters(O, monkeypatch):
@@ -163,6 +202,7 @@ def test_pipe_big_handover_of_running_clusters(O, monkeypatch):
     got = {}
     for donate in ("1", "0"):
         monkeypatch.setenv("CUBOID_ICP_DONATE", donate)
+        monkeypatch.setenv("CUBOID_ICP_DON_IDLE", "1" if donate == "1" else "0")   # workgroup 0 only ever works on hand-overs: not a matter of timing
         ctx = capi.Context(max_points=frames.shape[1], max_frames=len(frames))
         try:
             ctx.set_template(0, big)
