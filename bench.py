@@ -39,9 +39,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md: 8.0 TB/
 FP32_VALU_PEAK_TFLOPS = 157.3  # vector fp32 peak
 # Counter files of the current round under profiles/ (written by tools/profile_round.sh and tools/probe_icp_work.py on the
 # GPU box, copied into profiles/ and committed); the previous round's are the fallback until this round's exist.
-PMC_TRAFFIC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")   # HBM bytes per dispatch: separate --pmc FETCH_SIZE / WRITE_SIZE passes
-PMC_SQ_FILES = ("r04_pmc_icp.txt", "r03_pmc_icp.txt", "r02_pmc_icp.txt")                   # SQ counters per kernel (separate --pmc passes)
+PMC_TRAFFIC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json")   # HBM bytes per dispatch: separate --pmc FETCH_SIZE / WRITE_SIZE passes
+PMC_SQ_FILES = ("r05_pmc_icp.txt", "r04_pmc_icp.txt", "r03_pmc_icp.txt", "r02_pmc_icp.txt")                   # SQ counters per kernel (separate --pmc passes)
 ICP_WORK_FILES = ("r04_icp_work.json", "r03_icp_work.json")                                # executed distance tests of the dominant kernel (-DCD_STATS build)
+PMC_SQ_INFLIGHT_SHAPE_FILES = ("r05_pmc_icp_inflight_shape.txt",)   # the same passes with the launch shape of the timed region forced (CUBOID_LAT_SHAPE=4,2)
 VALU_CALIBRATION_FILES = ("r04_valu_calibration.json",)   # what the SQ counters read on a SATURATED vector pipe (tools/valu_calib.hip, same launch shape)
 WAVES_PER_SIMD_ICP = 4          # k_icp_pipe: one 1024-thread workgroup per CU = 16 waves = 4 per SIMD
 SIMDS = 1024                    # 256 CUs x 4
@@ -55,10 +56,10 @@ def _first_profile(names):
     return None, None
 
 
-def sq_counters(kernel):
+def sq_counters(kernel, files=None):
     """SQ counters of `kernel` from the committed PMC summary (lines "<kernel> {...} dispatches n" per pass)."""
     import ast
-    name, path = _first_profile(PMC_SQ_FILES)
+    name, path = _first_profile(files or PMC_SQ_FILES)
     out = {}
     if not path:
         return None, out
@@ -107,6 +108,20 @@ def _same_as_oracle(rg, ro):
         if (a.size, a.iterations, a.converged, a.accepted, bytes(a.T), a.fitness) != (b.size, b.iterations, b.converged, b.accepted, bytes(b.T), b.fitness):
             return False
         if float(np.linalg.norm(np.array(a.pose) - np.array(b.pose))) >= 1e-4:
+            return False
+    return True
+
+
+def _same_as_oracle_best_of(rg, per):
+    """template_slot = -1: `per` = the oracle's record of the frame against each template alone; per cluster the lowest fitness wins"""
+    ro = per[0]
+    if (rg.status, rg.n_cropped, rg.n_voxels, rg.n_plane, rg.n_objects, rg.n_clusters, rg.ransac_iterations) != \
+       (ro.status, ro.n_cropped, ro.n_voxels, ro.n_plane, ro.n_objects, ro.n_clusters, ro.ransac_iterations) or bytes(rg.plane) != bytes(ro.plane):
+        return False
+    for k in range(min(ro.n_clusters, len(ro.clusters))):
+        want = min(range(len(per)), key=lambda s_: (per[s_].clusters[k].fitness, s_))
+        a, b = rg.clusters[k], per[want].clusters[k]
+        if a.template_slot != want or (a.size, a.iterations, a.converged, a.accepted, bytes(a.T), a.fitness) != (b.size, b.iterations, b.converged, b.accepted, bytes(b.T), b.fitness):
             return False
     return True
 
@@ -503,18 +518,20 @@ def main():
     verified = None
     serial_rec = None
     serial_t = None
+    serial_ts = []
     if not args.no_verify:
         fence()
         res = (capi.CdFrameResult * F)()
         ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
         serial_rec = capi.results_to_array(res).copy()
         serial_t = ctx.timing()
+        serial_ts = [serial_t] if serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0 else []
         for _ in range(4 if M > 1 else 0):   # (a few more for the timing: the first pass after the pipelined region still finds the
-            # other contexts' data in L2, and a lone launch varies by ~3 % from one to the next; the fastest of five is kept)
+            # other contexts' data in L2, and a lone launch varies by ~3 % from one to the next; the MEDIAN of the five is reported)
             ctx.process_batch_device(d_frames.data_ptr(), 16, N, F, prm, results=res)
             t2 = ctx.timing()
-            if 0 < t2.icp_kernel_ms < serial_t.icp_kernel_ms:
-                serial_t = t2
+            if t2.icp_kernel_launches == 1 and t2.icp_kernel_ms > 0:
+                serial_ts.append(t2)
         ok = bool(np.array_equal(serial_rec, allrec[rank * F:(rank + 1) * F]))
         if use_dist:
             tv = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
@@ -578,10 +595,82 @@ def main():
             cb.close()
         except Exception as e:
             legs_out["big_template_ms"] = {"error": repr(e)}
+        # (2b) the generic (pruned) search on the headline's own batch and template: the same pipeline with CUBOID_ICP_LATTICE=0 -
+        # what a template that is NOT a lattice of this size costs, and the A/B of the closed form
+        pipe.close()
+        pipe = None
+        try:
+            os.environ["CUBOID_ICP_LATTICE"] = "0"
+            pg = batch.BatchPipeline(N, F, tpl_by_slot, device_id=local_rank, inflight=M)
+            os.environ.pop("CUBOID_ICP_LATTICE")
+            pump(pg, d_frames.data_ptr(), N, F, prm, 2 * M)
+            grec, gs = pump(pg, d_frames.data_ptr(), N, F, prm, 60)
+            legs_out["generic_search"] = {"frames_per_s": F * 60 / gs, "ms_per_step": gs / 60 * 1e3, "steps": 60, "batches_in_flight": M,
+                                          "records_identical_to_the_timed_path": bool(np.array_equal(grec, allrec[rank * F:(rank + 1) * F])),
+                                          "icp_search": int(pg.contexts[0].timing().icp_search),
+                                          "note": "the headline's batch with CUBOID_ICP_LATTICE=0: k_icp_pipe's pruned search (grid walk + k-d patches) over the "
+                                                  "same 7250-point template; outside `value`"}
+            pg.close()
+        except Exception as e:
+            os.environ.pop("CUBOID_ICP_LATTICE", None)
+            legs_out["generic_search"] = {"error": repr(e)}
+        # (2c) the object_detection flavour (object_detection.launch:30-38: voxel_size 0.001, distance_threshold 0.01; opd.cpp:331-336
+        # second z crop; opd.cpp:376-413 every cluster against every object template): the reference's four scanned templates
+        # (tests/golden/*_ascii_tf.pcd - arbitrary clouds, so the pruned searches run), 64 frames per batch
+        try:
+            from perception_amd import pcd
+            names = ("eraser", "clamp", "screwdriver", "marker")
+            tplo = {k: pcd.read_xyz(os.path.join(ROOT, "tests", "golden", nm + "_ascii_tf.pcd")).astype(np.float32) for k, nm in enumerate(names)}
+            prmo = capi.default_params()
+            prmo.rgb_offset = 12
+            prmo.leaf_size = 0.001
+            prmo.plane_distance_threshold = 0.01
+            prmo.template_slot = -1
+            Fo, Mo, Ko = 64, 4, 24
+            po = batch.BatchPipeline(N, Fo, tplo, device_id=local_rank, inflight=Mo)
+            pump(po, d_frames.data_ptr(), N, Fo, prmo, 2 * Mo)
+            orec, osec = pump(po, d_frames.data_ptr(), N, Fo, prmo, Ko)
+            ro_ = (capi.CdFrameResult * Fo)()
+            po.contexts[0].process_batch_device(d_frames.data_ptr(), 16, N, Fo, prmo, results=ro_)      # strictly serial pass
+            to_ = po.contexts[0].timing()
+            ok_serial = bool(np.array_equal(capi.results_to_array(ro_)[:Fo], orec))
+            ok_oracle = None
+            if not args.no_cpu_baseline:
+                from oracle import oracle_py as O      # allowed: the checker of a bench leg
+                from concurrent.futures import ThreadPoolExecutor
+                O.lib()
+                sample = list(range(0, Fo, 4))
+                tl = [tplo[k] for k in range(len(names))]
+                import copy
+
+                def oracle_frame(f):   # every template on its own, as the oracle runs them; the lowest fitness wins (ties: lowest slot)
+                    per = []
+                    for slot_, t_ in enumerate(tl):
+                        pr_ = copy.copy(prmo)
+                        pr_.template_slot = slot_
+                        per.append(O.process_frame(frames[f], pr_, t_)["result"])
+                    return per
+                with ThreadPoolExecutor(max(1, min(16, os.cpu_count() or 1))) as ex:
+                    want = list(ex.map(oracle_frame, sample))
+                ok_oracle = all(_same_as_oracle_best_of(ro_[f], w) for f, w in zip(sample, want))
+            legs_out["object_launch"] = {
+                "frames_per_s": Fo * Ko / osec, "ms_per_step": osec / Ko * 1e3, "frames_per_batch": Fo, "steps": Ko, "batches_in_flight": Mo,
+                "n_voxels_mean": float(np.mean([ro_[f].n_voxels for f in range(Fo)])), "clusters": int(sum(ro_[f].n_clusters for f in range(Fo))),
+                "templates": {nm: int(len(tplo[k])) for k, nm in enumerate(names)}, "icp_search": int(to_.icp_search),
+                "serial_stage_ms": {"crop_voxel": to_.stage_ms[0], "plane": to_.stage_ms[1], "extract_cluster": to_.stage_ms[2], "icp": to_.stage_ms[3], "total": to_.stage_ms[4]},
+                "verified": ok_serial, "oracle_sample_ok": ok_oracle, "oracle_sample_frames": (Fo // 4) if ok_oracle is not None else 0,
+                "note": "object_detection.launch parameters (leaf 0.001, plane threshold 0.01, second z crop) on the bench frames, every cluster "
+                        "against the reference's four scanned object templates, lowest fitness wins; verified = the last pipelined batch equals a "
+                        "strictly serial pass; oracle_sample_ok = every 4th frame equals the CPU oracle (counts, plane bits, T bits, fitness); "
+                        "outside `value`"}
+            po.close()
+        except Exception as e:
+            legs_out["object_launch"] = {"error": repr(e)}
         # (3) BASELINE config 5: 1 M-point frames, five cuboids, five templates, every cluster against every template.  The headline's
         # pipeline is closed first (its arenas are not needed any more; what slowed this leg down was the process's hardware-queue
         # budget, see DEFAULT_HW_QUEUES).
-        pipe.close()
+        if pipe is not None:
+            pipe.close()
         pipe = None
         try:
             from perception_amd import synth
@@ -626,86 +715,96 @@ def main():
         # HBM bytes per ICP kernel launch from the PMC passes (profiles/r01_pmc_traffic.json: separate
         # FETCH_SIZE / WRITE_SIZE runs of this same workload, gfx950 x2 FETCH correction applied)
         traffic = None
-        # whole-cluster mode: ONE persistent launch per batch (k_icp_pipe; k_icp_cluster when forced or when the
-        # template does not fit LDS); sliced mode: one k_icp_iter per iteration
+        # The dominant kernel: k_icp_lat when the template is a lattice (closed-form nearest neighbour, cd_timing.icp_search = 1);
+        # otherwise the pruned searches - whole-cluster mode: ONE persistent launch per batch (k_icp_pipe; k_icp_cluster when
+        # forced or when the template does not fit LDS); sliced mode: one k_icp_iter per iteration
         whole = icp_launches == args.steps
-        icp_kernel = ("k_icp_cluster" if os.environ.get("CUBOID_ICP_MODE") == "cluster" else "k_icp_pipe") if whole else "k_icp_iter"
+        lattice = bool(timings) and all(t.icp_search == 1 for t in timings)
+        icp_kernel = "k_icp_lat" if lattice else (("k_icp_cluster" if os.environ.get("CUBOID_ICP_MODE") == "cluster" else "k_icp_pipe") if whole else "k_icp_iter")
         traffic_file, tpath = _first_profile(PMC_TRAFFIC_FILES)
         try:
             pmc = json.load(open(tpath))
             if F == 256 and N == 307200:
                 traffic = pmc["kernels"][icp_kernel]["hbm_bytes_per_dispatch"]
         except (OSError, KeyError, ValueError, TypeError):
-            pass
-        # With M batches in flight the persistent launches of several batches share the chip: the per-launch duration of the
-        # timed region is then longer than the kernel's cost (8.89 ms per launch against 5.48 ms per step).  The
-        # headline achieved / frac therefore use the duration of ONE launch on an otherwise idle GPU - the strictly serial pass of
-        # the self-check after the timed region, HIP events on the context's stream like the timed launches, <= ms_per_step -
-        # and the overlapped figure is the secondary one (`in_flight`).
+            traffic, traffic_file = None, None
+        # `achieved` / `frac` / `avg_launch_ms` have ONE definition (the contract's): algorithmic bytes per launch over the average
+        # duration of the kernel's launches INSIDE the timed region (HIP events on the launch's stream).  With M batches in flight
+        # those launches share the chip with the other batches' kernels (`launches_in_flight` of them at any time), so the
+        # duration is queueing plus work; the same kernel with the GPU to itself is under the fixed key `exclusive` (median of
+        # the serial passes after the timed region; its launch shape differs: `regime`).  (no key changes meaning.)
         overlap = (icp_ms * 1e-3) / elapsed if elapsed > 0 else None
-        in_flight = {"avg_launch_ms": avg_launch_ms, "achieved": achieved, "frac": achieved / HBM_PEAK_GBS, "launches_in_flight": overlap,
-                     "note": "the same kernel's launches inside the timed region (HIP events): `launches_in_flight` of them share the chip at any "
-                             "time, so this duration is queueing plus work"}
-        excl_ms = None
-        regime = None
-        if serial_t is not None and serial_t.icp_kernel_launches == 1 and serial_t.icp_kernel_ms > 0:
-            excl_ms = float(serial_t.icp_kernel_ms)
-            regime = {"slots": serial_t.icp_regime >> 16, "workgroups": serial_t.icp_regime & 0xffff, "handovers": int(getattr(serial_t, "icp_handovers", 0))}
-        head_ms = excl_ms if excl_ms is not None else avg_launch_ms
-        head_achieved = per_launch_bytes / (head_ms * 1e-3) / 1e9
+
+        def _regime(t):
+            return {"clusters_per_workgroup": t.icp_regime >> 16, "workgroups": t.icp_regime & 0xffff, "handovers": int(t.icp_handovers),
+                    "search": {0: "pruned (generic template)", 1: "lattice closed form", 2: "both"}.get(int(t.icp_search), "?")}
         timed_regime = None
-        if timings:   # the shape most launches of the timed region had (the last ones, with the pipeline draining, fall back to 2 x 256)
+        if timings and any(t.icp_regime for t in timings):   # the shape most launches of the timed region had
             import collections
-            reg, cnt = collections.Counter(t.icp_regime for t in timings if t.icp_regime).most_common(1)[0] if any(t.icp_regime for t in timings) else (0, 0)
-            if reg:
-                timed_regime = {"slots": reg >> 16, "workgroups": reg & 0xffff, "launches": cnt, "of": len(timings)}
-        # What bounds the dominant kernel.  Its working set is LDS/L2-resident (traffic = 0.37 x algorithmic bytes), so HBM is not
-        # its roof; the SQ counters (committed, collected by tools/profile_round4.sh on ONE launch alone: the regime of `achieved`)
-        # are read against what the same counters show on a SATURATED vector pipe at the same launch shape
-        # (profiles/r04_valu_calibration.json, tools/valu_calib.hip): both round 3's formula and the first-principles one are
-        # reported, raw and as a fraction of their saturation value.
-        sq_file, sq = sq_counters(icp_kernel)
+            reg, cnt = collections.Counter(t.icp_regime for t in timings if t.icp_regime).most_common(1)[0]
+            timed_regime = dict(_regime(next(t for t in timings if t.icp_regime == reg)), launches=cnt, of=len(timings))
+        exclusive = None
+        if serial_ts:
+            ex_ms = float(np.median([t.icp_kernel_ms for t in serial_ts]))
+            exclusive = {"avg_launch_ms": ex_ms, "avg_launch_ms_is": "median of %d launches alone on an idle GPU (serial passes after the timed region)" % len(serial_ts),
+                         "achieved": per_launch_bytes / (ex_ms * 1e-3) / 1e9, "frac": per_launch_bytes / (ex_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "regime": _regime(serial_ts[0]),
+                         "wave_ms_per_launch": float(np.median([t.icp_wave_ms for t in serial_ts])) if lattice else None}
+        # What a batch's ICP costs with batches in flight is not the launch's duration but the WAVE-TIME it holds: sum over the
+        # launch's workgroups of lifetime x waves (cd_timing.icp_wave_ms, measured by the kernel itself), against the chip's wave
+        # slots at this kernel's register count (256 CUs x 16).
+        wave_time = None
+        if lattice and timings:
+            wm = float(np.mean([t.icp_wave_ms for t in timings]))
+            wave_time = {"wave_ms_per_batch": wm, "chip_wave_slots": 256 * 16, "chip_ms_per_batch": wm / (256 * 16),
+                         "frac_of_step": wm / (256 * 16) / ms_per_step,
+                         "note": "sum over the ICP launch's workgroups of (lifetime x waves), measured in the kernel (100 MHz clock): the share "
+                                 "of the chip's wave slots (256 CUs x 16 waves at this kernel's 128 registers) a batch's ICP holds for one step"}
+        # What bounds the dominant kernel: neither HBM (traffic: a tenth of the algorithmic bytes, the clusters stay in L2) nor vector
+        # issue - the committed SQ counters (tools/profile_round5.sh: one launch alone, for both launch shapes) against the
+        # saturated vector rate of the same chip (profiles/r04_valu_calibration.json, tools/valu_calib.hip).
         valu = None
         bound = "hbm"
-        if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_ACTIVE_INST_VALU") and sq.get("SQ_INSTS_VALU") and args.config == 3:
-            cname, cpath = _first_profile(VALU_CALIBRATION_FILES)
-            cal = json.load(open(cpath)) if cpath else None
-            wave_cycles = sq["SQ_WAVE_CYCLES"] * 4.0 / (256 * 16)       # quad-cycles summed over 4096 waves -> cycles of one wave's life
-            A = sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"] * WAVES_PER_SIMD_ICP
-            B = sq["SQ_INSTS_VALU"] * 2.0 / (SIMDS * wave_cycles)
-            valu = {"counters_file": "profiles/" + sq_file, "calibration_file": ("profiles/" + cname) if cname else None,
-                    "regime_of_the_counters": "one launch alone (bench.py --steps 1 --warmup 0): 2 slots x 256 workgroups, the regime of roofline.achieved",
-                    "SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_ACTIVE_INST_VALU": sq["SQ_ACTIVE_INST_VALU"], "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"],
-                    "waves_per_simd": WAVES_PER_SIMD_ICP,
-                    "A_active_over_wave_cycles_x_waves": A, "B_insts_x2_over_simd_cycles": B,
-                    "salu_per_valu": (sq.get("SQ_INSTS_SALU", 0.0) / sq["SQ_INSTS_VALU"]),
+        cname, cpath = _first_profile(VALU_CALIBRATION_FILES)
+        cal = json.load(open(cpath)) if cpath else None
+
+        def _valu_block(files, launch_ms, shape):
+            sq_file, sq = sq_counters(icp_kernel, files)
+            if not (sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_INSTS_VALU") and launch_ms):
+                return None
+            out_ = {"counters_file": "profiles/" + sq_file, "launch_shape_of_the_counters": shape, "launch_ms_used": launch_ms,
+                    "SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_INSTS_SALU": sq.get("SQ_INSTS_SALU"), "SQ_INSTS_LDS": sq.get("SQ_INSTS_LDS"),
+                    "SQ_INSTS_VMEM": sq.get("SQ_INSTS_VMEM"), "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"], "SQ_WAVES": sq.get("SQ_WAVES"),
+                    "valu_active_frac_of_wave_life": (sq["SQ_ACTIVE_INST_VALU"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_ACTIVE_INST_VALU") else None,
                     "wait_any_frac": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_ANY") else None,
                     "wait_inst_any_frac": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_INST_ANY") else None,
-                    "active_inst_any_frac": (sq["SQ_ACTIVE_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_ACTIVE_INST_ANY") else None}
+                    "lds_bank_conflict_frac_of_lds_active": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") and sq.get("SQ_LDS_BANK_CONFLICT") else None,
+                    "vector_instructions_per_query_iteration": (sq["SQ_INSTS_VALU"] * 64.0 / (icp_balg / max(icp_launches / args.steps, 1) / 12.0)) if icp_balg else None}
             if cal:
-                sat, mix = cal["saturation"], cal["saturation_search_mix"]
-                valu.update({"A_at_saturation": sat["A"], "B_at_saturation": sat["B"],
-                             "pipe_frac": B / sat["B"], "pipe_frac_vs_search_mix": B / mix["B"],
-                             "note": "pipe_frac = B / B_at_saturation = A / A_at_saturation: the share of the saturated f32 vector rate (independent "
-                                     "v_fma_f32, four waves per SIMD) this kernel issues; against a stream of its own instruction mix (LDS reads, 64-bit "
-                                     "key minima) pipe_frac_vs_search_mix.  Round 3 printed A as 'issue_frac 0.86': A reads 2.36, not 1.0, when the "
-                                     "pipe is full.  The counters are of ONE launch alone on the GPU, which since the second half of round 4 keeps "
-                                     "the workgroups that ran out of clusters waiting inside the launch (hand-overs): their parked waves count in "
-                                     "SQ_WAVE_CYCLES (8.2e9 -> 1.0e10 for the same 1.95e9 vector instructions), so the per-wave-cycle rates read a "
-                                     "fifth lower than the 0.40 of a launch whose idle workgroups end"})
-                pf = valu["pipe_frac"]
-                bound = "valu" if pf >= 0.8 else "latency"
-            wname, wpath = _first_profile(ICP_WORK_FILES)
-            if wpath:
-                try:
-                    w = json.load(open(wpath))
-                    fl = float(w["executed_flops"])
-                    valu.update({"work_file": "profiles/" + wname, "executed_pair_tests": w["executed_pair_tests"]["total"],
-                                 "flops_per_test": w["flops_per_pair_test"], "executed_flops_per_launch": fl,
-                                 "achieved_tflops": fl / (head_ms * 1e-3) / 1e12,
-                                 "frac_of_157.3_TFLOPs": fl / (head_ms * 1e-3) / 1e12 / FP32_VALU_PEAK_TFLOPS})
-                except (OSError, KeyError, ValueError):
-                    pass
+                sat = cal["saturation"]["valu_per_ns_per_simd"]
+                out_["pipe_frac"] = sq["SQ_INSTS_VALU"] / (SIMDS * launch_ms * 1e6 * sat)
+                out_["saturated_valu_per_ns_per_simd"] = sat
+                out_["calibration_file"] = "profiles/" + cname
+            return out_
+        if args.config == 3 and lattice:
+            v_in = _valu_block(PMC_SQ_INFLIGHT_SHAPE_FILES, avg_launch_ms, "4 clusters x 2 waves per workgroup (forced with CUBOID_LAT_SHAPE=4,2: the shape of the timed region), one launch alone - counters serialise kernels")
+            v_ex = _valu_block(PMC_SQ_FILES, exclusive["avg_launch_ms"] if exclusive else None, "1 cluster x 4 waves per workgroup: the shape a call with the GPU to itself picks")
+            if v_in or v_ex:
+                valu = {"in_flight_shape": v_in, "exclusive_shape": v_ex,
+                        "note": "pipe_frac = vector wave-instructions of the launch / (1024 SIMDs x launch duration x the saturated vector rate of "
+                                "profiles/r04_valu_calibration.json): for in_flight_shape the duration is the timed region's (the chip is shared), for "
+                                "exclusive_shape the lone launch's.  The closed-form search issues ~5x fewer vector instructions than round 4's pruned "
+                                "search (3.8e8 against 1.95e9 per launch); what is left is a chain: per round of a cluster ~19 us of passes on one wave "
+                                "and ~6.5 us of single-lane solve (tools/probe_lat_phases.py, profiles/r05_lat_phases.txt)"}
+                pf = (v_in or v_ex).get("pipe_frac")
+                bound = "valu" if (pf or 0) >= 0.8 else "latency"
+        elif args.config == 3:
+            sq_file, sq = sq_counters(icp_kernel, ("r04_pmc_icp.txt",))
+            if sq.get("SQ_WAVE_CYCLES") and sq.get("SQ_INSTS_VALU"):
+                valu = {"counters_file": "profiles/" + sq_file, "SQ_INSTS_VALU": sq["SQ_INSTS_VALU"], "SQ_WAVE_CYCLES": sq["SQ_WAVE_CYCLES"],
+                        "wait_any_frac": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_ANY") else None,
+                        "note": "generic (pruned) search: round 4's counters of one launch alone, see profiles/r04_pmc_icp.txt and DESIGN.md"}
+                bound = "latency"
         if os.environ.get("CUBOID_BENCH_ICP_ITERS"):
             print("bench.py: CUBOID_BENCH_ICP_ITERS is set - an EXPERIMENT with the ICP cut short, not the metric", file=sys.stderr)
         out = {
@@ -726,28 +825,29 @@ def main():
                        "frames_per_gpu": F, "points_per_frame": int(N), "template_points": int(len(tpl)),
                        "batches_in_flight": M,
                        "sharding": "frame-per-GPU, one all_gather of %d-byte records per batch" % capi.FRAME_RESULT_BYTES},
-            "roofline": {"kernel": icp_kernel, "bound": bound, "achieved": head_achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": head_achieved / HBM_PEAK_GBS, "traffic": traffic,
+            "roofline": {"kernel": icp_kernel, "bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_file": ("profiles/" + traffic_file) if traffic is not None else None,
                          "traffic_note": "HBM bytes of one launch from the committed counter file (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                          "this workload, gfx950 x2 FETCH correction; counters cannot be collected inside this run)",
-                         "avg_launch_ms": head_ms, "avg_launch_ms_is": "one launch alone on an idle GPU (fastest of five serial passes after the timed region)" if excl_ms is not None else
-                                                                        "launches of the timed region (no serial pass: --no-verify)",
-                         "launches_per_step": icp_launches / args.steps,
+                         "avg_launch_ms": avg_launch_ms,
+                         "avg_launch_ms_is": "the kernel's launches INSIDE the timed region (HIP events on the launch's stream), batches in flight",
+                         "launches_in_flight": overlap, "launches_per_step": icp_launches / args.steps,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "regime": regime, "in_flight": in_flight, "in_flight_regime": timed_regime,
+                         "regime": timed_regime, "exclusive": exclusive, "wave_time": wave_time,
                          "valu": valu,
-                         "note": "achieved/frac: algorithmic bytes of the dominant kernel (SURVEY 8(d): 12 M + 12 N_s (I + 1) per cluster) over the "
-                                 "duration of ONE launch with the GPU to itself, against the HBM peak as the contract defines the block - a duration "
-                                 "that is the kernel's cost (<= ms_per_step); `in_flight` = the same over the launches of the timed region, which "
-                                 "overlap.  `bound`: HBM is not this kernel's roof (traffic < algorithmic bytes: the working set is LDS/L2-resident) "
-                                 "and, measured against a saturated pipe, neither is vector issue (valu.pipe_frac): its waves sit at s_waitcnt / "
-                                 "s_sleep for valu.wait_any_frac of their life - dependent LDS round trips and scalar/vector hand-overs (DESIGN.md "
-                                 "section 4)"},
-            "icp_search": {"kernel": icp_kernel, "bruteforce_equivalent_pair_tests_per_step": pairs,
+                         "note": "achieved / frac: algorithmic bytes of the dominant kernel (SURVEY 8(d): 12 M + 12 N_s (I + 1) per cluster) over the average "
+                                 "duration of its launches in the timed region, against the HBM peak as the contract defines the block; `exclusive` = the same "
+                                 "for a launch that has the GPU to itself.  `bound`: HBM is not this kernel's roof (traffic is a fraction of the algorithmic "
+                                 "bytes: the clusters stay in L2, the template is a few hundred table entries in LDS) and neither is vector issue "
+                                 "(valu.*.pipe_frac): every cluster is a chain of ~70 rounds, each a pass over its points and a single-lane 3x3 SVD "
+                                 "(DESIGN.md section 4).  With batches in flight a batch's ICP costs the chip `wave_time.chip_ms_per_batch`"},
+            "icp_search": {"kernel": icp_kernel, "search": "lattice closed form (k_icp_lat.hip)" if lattice else "pruned search over an arbitrary template (k_icp.hip)",
+                           "bruteforce_equivalent_pair_tests_per_step": pairs,
                            "bruteforce_equivalent_pair_tests_per_s": pairs / (icp_ms / args.steps * 1e-3) if icp_ms else None,
-                           "note": "exact search by pruning (lane-per-query grid walk for near queries, wave-per-query k-d patch search for far ones): "
-                                   "the brute-force-equivalent rate is NOT executed work; executed tests and the issue-slot occupancy are in roofline.valu",
+                           "note": "the nearest neighbour of every query is exact in both searches (same neighbour, same lowest-index tie rule as a brute "
+                                   "force); the brute-force-equivalent rate is NOT executed work.  CUBOID_ICP_LATTICE=0 runs the pruned search on the same "
+                                   "template: `generic_search` below",
                            "fp32_valu_peak_tflops": FP32_VALU_PEAK_TFLOPS},
             "pipeline_hbm": {"algorithmic_bytes_per_frame": balg / F, "achieved_GBps": balg / F * value / world / 1e9,
                              "frac_of_peak": balg / F * value / world / 1e9 / HBM_PEAK_GBS},
@@ -766,6 +866,7 @@ def main():
                                               "the kept records; host wall clock of the synchronous C-ABI call"} if len(lat_host) > 2 else None),
             "guess_leg": guess_leg,
             "host_fed": legs_out.get("host_fed"), "big_template_ms": legs_out.get("big_template_ms"), "config5": legs_out.get("config5"),
+            "generic_search": legs_out.get("generic_search"), "object_launch": legs_out.get("object_launch"),
             "cu_fill_debug": cu_fill,
             "verified": verified,
             "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "

@@ -354,7 +354,10 @@ typedef struct cd_timing {
     int32_t icp_handover_lost;                    /* a cluster in hand-over between two workgroups was claimed and never arrived, or a waiting
                                                    * workgroup ran out of polls: the call has FAILED with CD_ERR_DEVICE (its records are not
                                                    * complete).  Cannot happen in a healthy launch; 0 otherwise                              */
-    int32_t reserved;
+    float icp_wave_ms;                            /* lattice ICP launches: sum over the launch's workgroups of (lifetime x waves), in
+                                                   * wave-milliseconds - what the batch's ICP held of the chip's wave slots (256 CUs x 16
+                                                   * waves at this kernel's register count); with batches in flight this, not the launch's
+                                                   * duration, is what a batch's ICP costs.  0 for the other ICP drivers                     */
 } cd_timing;
 int cd_get_timing(const cd_context* ctx, cd_timing* out);
 

@@ -96,7 +96,7 @@ class CdTiming(C.Structure):
         ("algorithmic_bytes", C.c_int64), ("icp_algorithmic_bytes", C.c_int64),
         ("scan_retries", C.c_int32), ("icp_regime", C.c_int32),
         ("icp_handovers", C.c_int32), ("icp_search", C.c_int32),
-        ("icp_handover_lost", C.c_int32), ("reserved", C.c_int32),
+        ("icp_handover_lost", C.c_int32), ("icp_wave_ms", C.c_float),
     ]
 
 

@@ -273,7 +273,7 @@ int ensure_clusters(cd_context* c, int ncl, long long points) {
     HIPCHK(c, dalloc(&c->d_work, w)); HIPCHK(c, halloc(&c->h_work, w));
     HIPCHK(c, dalloc(&c->d_work2, w)); HIPCHK(c, halloc(&c->h_work2, w));
     HIPCHK(c, dalloc(&c->d_st, n * 2)); HIPCHK(c, halloc(&c->h_st, n * 2));
-    HIPCHK(c, dalloc(&c->d_acc, n * 48)); HIPCHK(c, dalloc(&c->d_accf, n)); HIPCHK(c, halloc(&c->h_accf, n));
+    HIPCHK(c, dalloc(&c->d_acc, n * 48)); HIPCHK(c, dalloc(&c->d_accf, n + 1)); HIPCHK(c, halloc(&c->h_accf, n + 1));   // (+ 1: k_icp_lat's wave-time word)
     c->cl_cap = (int)n;
     c->work_cap = (int)w;
     return CD_OK;
@@ -661,7 +661,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, hipMemcpyAsync(c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
+    HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * ((size_t)ncl + 1), c->stream));   // (+ the wave-time word of k_icp_lat)
     if (guess_mode != CD_GUESS_NONE)   // input_transformed = guess * source (d_src is a copy of d_src0 at this point)
         LAUNCH(c, launch_icp_apply_guess(c->stream, ncl, max_n, c->d_cl, c->d_guess, guess_mode == CD_GUESS_PER_FRAME ? 1 : 0, c->d_src0, c->d_src));
     IcpParams ip;
@@ -713,17 +713,18 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         if (c->lat_shape[0] > 0) { cpw = c->lat_shape[0]; wpc = std::max(1, c->lat_shape[1]); per_slot = std::max(1, c->lat_shape[2]); }
         const int n_wg = std::max(1, (n_lat + cpw * per_slot - 1) / (cpw * per_slot));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
-        LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, ip));
+        LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, ip));
         c->timing.icp_kernel_launches = 1;
         c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
         HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
         if (n_lat == n_live) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost, c->stream));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             float ms1 = 0.f;
             hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
             c->timing.icp_kernel_ms = ms1;
+            c->timing.icp_wave_ms = (float)((double)c->h_accf[ncl] / 1.0e5);   // 100 MHz ticks x waves -> wave-milliseconds
             if (pair_tests) {
                 long long tot = 0;
                 for (int k = 0; k < ncl; ++k)
@@ -1460,7 +1461,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_st, ncl * 2) == hipSuccess && halloc(&c->h_st, ncl * 2) == hipSuccess;
-    ok = ok && dalloc(&c->d_acc, ncl * 48) == hipSuccess && dalloc(&c->d_accf, ncl) == hipSuccess && halloc(&c->h_accf, ncl) == hipSuccess;
+    ok = ok && dalloc(&c->d_acc, ncl * 48) == hipSuccess && dalloc(&c->d_accf, ncl + 1) == hipSuccess && halloc(&c->h_accf, ncl + 1) == hipSuccess;
     if (ok) {
         // PCL's SAC sampler: boost::mt19937 seeded 12345, uniform_int<>(0, INT_MAX) == mt() >> 1
         std::vector<int> tab((size_t)RND_TABLE);

@@ -262,7 +262,7 @@ template <int CPW, int WPC>
 __global__ void __launch_bounds__(CPW * WPC * WAVE, CD_LAT_WAVES_PER_EU)
 k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
           unsigned long long* __restrict__ accf, const IcpLattice* __restrict__ lats, float4* __restrict__ src,
-          const float4* __restrict__ src0, int* __restrict__ queue, IcpParams prm) {
+          const float4* __restrict__ src0, int* __restrict__ queue, unsigned long long* __restrict__ busy, IcpParams prm) {
     constexpr int THREADS = CPW * WPC * WAVE;
     __shared__ float4 s_tab[CPW][LAT_MAX_TAB];
     __shared__ int4 s_face[CPW][2 * LAT_MAX_FACES];
@@ -272,6 +272,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
     __shared__ int s_flags[2];   // [0] every slot is empty, [1] some slot was refilled in this round
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int slot = wave / WPC, sub = wave % WPC;
+    const long long wg_t0 = wall_clock64();   // (100 MHz: the workgroup's lifetime goes to accf[nitems_all], see the end)
     // refill of slot s by one lane: the next live cluster of the queue (largest first), or nothing left
     auto refill = [&](int s) {
         LatSlot& sl = s_slot[s];
@@ -455,6 +456,9 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
 #ifdef CD_LAT_TIMERS
     if (threadIdx.x == 0) for (int i = 0; i < 6; ++i) atomicAdd(&g_lat_stats[i], (unsigned long long)tph[i]);
 #endif
+    // the wave-time this launch cost: lifetime of the workgroup (100 MHz ticks) x its waves, summed over the workgroups
+    // (cd_timing.icp_wave_ms: what a batch's ICP holds of the chip's wave slots, the throughput roof with batches in flight)
+    if (threadIdx.x == 0 && busy) atomicAdd(busy, (unsigned long long)(wall_clock64() - wg_t0) * (unsigned long long)(CPW * WPC));
 }
 
 // diagnostic / test entry: nearest template point of arbitrary queries (original index and canonical d2)
@@ -476,19 +480,19 @@ __global__ void __launch_bounds__(BLOCK) k_lat_nn(const IcpLattice* __restrict__
 // shape = clusters per workgroup * 256 + waves per cluster (1 | 2 | 4 | 8 x 1 | 2 | 4 | 8 | 16, at most 16 waves per workgroup)
 template <int CPW, int WPC>
 static void launch_lat_shape(hipStream_t s, int nitems, int n_wg, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
-                             const IcpLattice* lats, float4* src, const float4* src0, int* queue, IcpParams prm) {
-    hipLaunchKernelGGL((k_icp_lat<CPW, WPC>), dim3(n_wg), dim3(CPW * WPC * WAVE), 0, s, nitems, order, cl, st, accf, lats, src, src0, queue, prm);
+                             const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy, IcpParams prm) {
+    hipLaunchKernelGGL((k_icp_lat<CPW, WPC>), dim3(n_wg), dim3(CPW * WPC * WAVE), 0, s, nitems, order, cl, st, accf, lats, src, src0, queue, busy, prm);
 }
 void launch_icp_lat(hipStream_t s, int nitems, int cpw, int wpc, int n_wg, const int* order, const IcpCluster* cl, IcpState* st,
-                    unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, IcpParams prm) {
+                    unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy, IcpParams prm) {
     if (nitems <= 0 || n_wg <= 0) return;
-#define CD_LAT_CASE(C, W) if (cpw == C && wpc == W) return launch_lat_shape<C, W>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, prm);
+#define CD_LAT_CASE(C, W) if (cpw == C && wpc == W) return launch_lat_shape<C, W>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, prm);
     CD_LAT_CASE(1, 1) CD_LAT_CASE(1, 2) CD_LAT_CASE(1, 4) CD_LAT_CASE(1, 8) CD_LAT_CASE(1, 16)
     CD_LAT_CASE(2, 1) CD_LAT_CASE(2, 2) CD_LAT_CASE(2, 4)
     CD_LAT_CASE(4, 1) CD_LAT_CASE(4, 2) CD_LAT_CASE(4, 4)
     CD_LAT_CASE(8, 1) CD_LAT_CASE(8, 2)
 #undef CD_LAT_CASE
-    launch_lat_shape<1, 4>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, prm);
+    launch_lat_shape<1, 4>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, prm);
 }
 void launch_lat_nn(hipStream_t s, const IcpLattice* lat, const float4* q, int n, int* out_idx, float* out_d2) {
     if (n <= 0) return;

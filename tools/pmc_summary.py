@@ -1,9 +1,9 @@
-import csv, sys, glob, collections
+import csv, sys, glob, collections, re
 f = glob.glob(sys.argv[1] + '/**/*counter_collection.csv', recursive=True)[0]
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
 for r in csv.DictReader(open(f)):
-    name = r['Kernel_Name'].split('(')[0].replace('cd::', '')
+    name = re.sub(r'<.*>$', '', re.sub(r'^void\s+', '', r['Kernel_Name'].split('(')[0].replace('cd::', '')))   # (k_icp_lat<4, 2> -> k_icp_lat)
     agg[name][r['Counter_Name']] += float(r['Counter_Value'])
     cnt[(name, r['Counter_Name'])] += 1
 for name in sorted(agg, key=lambda n: -agg[n].get('SQ_WAVE_CYCLES', agg[n].get('SQ_WAVES', 0))):

@@ -8,6 +8,7 @@ import collections
 import csv
 import glob
 import json
+import re
 import sys
 
 
@@ -17,7 +18,7 @@ def load(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        name = r["Kernel_Name"].split("(")[0].replace("cd::", "")
+        name = re.sub(r"<.*>$", "", re.sub(r"^void\s+", "", r["Kernel_Name"].split("(")[0].replace("cd::", "")))   # (k_icp_lat<4, 2> -> k_icp_lat)
         tot[name] += float(r["Counter_Value"])
         cnt[name] += 1
     return tot, cnt

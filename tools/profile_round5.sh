@@ -22,11 +22,23 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc_traffic.json > /dev/null
 : > $OUT/pmc_icp.txt
-n=0
-for pass in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_WAVES"; do
-  n=$((n+1))
-  rm -rf /tmp/sq_$n && timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/sq_$n -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B > /tmp/sq_$n.log 2>&1
-  echo "== pass $n (--pmc $pass), bench.py --steps 1 --warmup 0 $B" >> $OUT/pmc_icp.txt
-  python3 $R/tools/pmc_summary.py /tmp/sq_$n | grep -E "^k_" >> $OUT/pmc_icp.txt
-  echo "sq pass $n done"
+: > $OUT/pmc_icp_inflight_shape.txt
+PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_WAVES")
+# two sets: the launch shape of a call that has the GPU to itself (1 cluster x 4 waves per workgroup: what the one-batch run picks by
+# itself) and the shape the launches of the timed region have (4 clusters x 2 waves, forced here; counters serialise the kernels,
+# so "under load" can only mean the shape)
+for set in "excl:" "inflight:CUBOID_LAT_SHAPE=4,2"; do
+  tag=${set%%:*}; envs=${set#*:}
+  out=$OUT/pmc_icp.txt; [ "$tag" = inflight ] && out=$OUT/pmc_icp_inflight_shape.txt
+  n=0
+  for pass in "${PASSES[@]}"; do
+    n=$((n+1))
+    rm -rf /tmp/sq_$n
+    if [ -n "$envs" ]; then export $envs; fi
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc $pass -d /tmp/sq_$n -o p --output-format csv -- python3 $R/bench.py --steps 1 --warmup 0 $B > /tmp/sq_$n.log 2>&1
+    unset CUBOID_LAT_SHAPE
+    echo "== pass $n (--pmc $pass), ${envs:-default shape} bench.py --steps 1 --warmup 0 $B" >> $out
+    python3 $R/tools/pmc_summary.py /tmp/sq_$n | grep -E "^k_" >> $out
+    echo "$tag sq pass $n done"
+  done
 done
