@@ -184,6 +184,16 @@ constexpr int DON_CAP = 2048;     // entries (a launch hands over a few hundred 
 // device helpers
 // ---------------------------------------------------------------------------------
 #ifdef __HIPCC__
+// Wave priority of the FRONT-END kernels (crop .. clusters).  With batches in flight their waves share SIMDs with the ICP's, whose
+// waves nearly always have a vector instruction ready: a SIMD picks among ready waves by priority first, so at equal priority
+// every front-end instruction queues behind the ICP's (tools/probe_interference.py: a resident FMA chain slows the front end
+// 3.5 x, parked waves of the same footprint 1.1 x).  The front end is latency-bound and short, the ICP a long chain that is not
+// what bounds the pipeline: the front end goes first (s_setprio 3; the ICP kernels stay at 0).  -DCD_NO_FRONT_PRIO: A/B.
+#ifndef CD_NO_FRONT_PRIO
+#define CD_FRONT_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define CD_FRONT_PRIO()
+#endif
 __device__ __forceinline__ uint32_t f2ord(float f) {
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);

@@ -92,10 +92,12 @@ struct cd_context {
     IcpLattice* d_lat = nullptr;                                  // per template slot: axis tables and faces of a lattice template (nface = 0: none)
     int tpl_faces[CD_MAX_TEMPLATES] = {0};                        // faces of the slot's lattice (0: the generic searches take it)
     int icp_lattice = 1;                                          // CUBOID_ICP_LATTICE=0: lattice templates take the generic searches too (A/B, fallback tests)
+    int copy_kernels = 1;                                         // CUBOID_COPY_KERNELS=0: the small pinned <-> device transfers go through hipMemcpyAsync (SDMA) again
     int lat_shape[3] = {0, 0, 0};                                 // CUBOID_LAT_SHAPE=cpw,wpc[,per_slot]: clusters per workgroup, waves per cluster, clusters per slot of k_icp_lat (0: by regime)
     hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
                                                                   // first (stream2); with icp_lowprio both are low-priority streams, so that CUs that come free go to the
                                                                   // short front-end kernels of the other batches in flight before the next persistent workgroup
+    int front_concurrent = 0;                                     // CUBOID_FRONT_CONCURRENT: at most that many fused batch calls of the device between crop and clusters (0 = no gate)
     int icp_concurrent = 0;                                       // CUBOID_ICP_CONCURRENT: admission gate of the whole-cluster ICP launches (0 = none)
     int icp_lowprio = 1;                                          // CUBOID_ICP_LOWPRIO: 0 never, 1 the launches of a mixed-template batch (measured: config 5 +30 %), 2 every
                                                                   // persistent ICP launch (config 3: -1 %)
@@ -196,6 +198,13 @@ struct IcpGate {
     void leave() { { std::lock_guard<std::mutex> lk(mu); --inside; } cv.notify_one(); }
 };
 IcpGate g_icp_gate[MAX_DEVICES];
+IcpGate g_front_gate[MAX_DEVICES];   // the same for the front end (crop .. clusters) of the fused batch calls: CUBOID_FRONT_CONCURRENT
+struct GateHold {   // (released on every path out of its scope)
+    IcpGate* g = nullptr;
+    void enter(IcpGate* gate, int k) { g = gate; g->enter(k); }
+    void release() { if (g) { g->leave(); g = nullptr; } }
+    ~GateHold() { release(); }
+};
 struct CallGuard {   // one per compute call: counts the contexts at work on the device (k_icp_persist wants the chip to itself)
     int dev;
     explicit CallGuard(int d) : dev(d & (MAX_DEVICES - 1)) { g_calls_in_flight[dev].fetch_add(1); }
@@ -242,6 +251,19 @@ static hipError_t copy_sync(cd_context* c, void* dst, const void* src, size_t by
     return hipStreamSynchronize(c->stream);
 }
 
+// a small transfer between a PINNED host mirror of the context and device memory, as a kernel on the context's stream
+// (launch_copy_rows, k_plane.hip: why not hipMemcpyAsync).  bytes: a multiple of 4.  CUBOID_COPY_KERNELS=0: hipMemcpyAsync (A/B).
+static hipError_t xfer(cd_context* c, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (!c->copy_kernels || (bytes & 3)) return hipMemcpyAsync(dst, src, bytes, kind, c->stream);
+    launch_copy_rows(c->stream, dst, bytes, src, bytes, bytes, 1);
+    return hipGetLastError();
+}
+static hipError_t xfer2d(cd_context* c, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows, hipMemcpyKind kind) {
+    if (!c->copy_kernels || (width & 3) || (dpitch & 3) || (spitch & 3)) return hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, c->stream);
+    launch_copy_rows(c->stream, dst, dpitch, src, spitch, width, rows);
+    return hipGetLastError();
+}
+
 int ensure_input(cd_context* c, size_t bytes) {
     if (bytes <= c->d_in_bytes) return CD_OK;
     if (c->d_in) hipFree(c->d_in);
@@ -280,7 +302,7 @@ int ensure_clusters(cd_context* c, int ncl, long long points) {
 }
 
 int sync_fs(cd_context* c, int F) {
-    HIPCHK(c, hipMemcpyAsync(c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, xfer(c, c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int f = 0; f < F; ++f)
         if (c->h_fs[f].scan_stalled) return fail(c, CD_INTERNAL_STALL, "a chained scan stalled (workgroups of a grid were not started in id order)");
@@ -339,7 +361,7 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // failed half way can never leave the next one with a counter that is not zero)
     HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int) * (size_t)F * TICKET_PITCH, c->stream));
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
         if (kp.enabled && crop_runs) {
             HIPCHK(c, hipMemsetAsync(c->d_tile64, 0, sizeof(unsigned long long) * (size_t)F * T, c->stream));
@@ -428,13 +450,13 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     for (int r = 0; r < 4; ++r) {
         const int h_target = std::min(targets[r], h_cap);
         if (h_target <= h_prev) break;
-        HIPCHK(c, hipMemcpyAsync(c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice));
         LAUNCH(c, launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, c->d_active, c->d_models, c->d_valid));
         LAUNCH(c, launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, c->d_active, h_prev, h_target, thr, c->d_counts));
         // only the first h_target columns of the [F][MAX_HYP] tables are live: one strided copy each
-        HIPCHK(c, hipMemcpy2DAsync(c->h_counts, sizeof(int) * MAX_HYP, c->d_counts, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpy2DAsync(c->h_valid, sizeof(int) * MAX_HYP, c->d_valid, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpy2DAsync(c->h_models, sizeof(float4) * MAX_HYP, c->d_models, sizeof(float4) * MAX_HYP, sizeof(float4) * h_target, F, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, xfer2d(c, c->h_counts, sizeof(int) * MAX_HYP, c->d_counts, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost));
+        HIPCHK(c, xfer2d(c, c->h_valid, sizeof(int) * MAX_HYP, c->d_valid, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost));
+        HIPCHK(c, xfer2d(c, c->h_models, sizeof(float4) * MAX_HYP, c->d_models, sizeof(float4) * MAX_HYP, sizeof(float4) * h_target, F, hipMemcpyDeviceToHost));
         int st = sync_fs(c, F);   // sync #2 (per round): counts + n_hyp
         if (st) return st;
         ++rounds;
@@ -472,15 +494,15 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
             const float mm[4] = {c->h_model[f].x, c->h_model[f].y, c->h_model[f].z, c->h_model[f].w};
             c->h_active[f] = c->h_have[f] && hm::plane_model_valid(p->plane_model, mm, p->plane_axis, p->plane_eps_angle) ? 1 : 0;
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice));
         return CD_OK;
     };
-    HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
     if (int st = upload_have()) return st;
     if (p->plane_optimize) {
         HIPCHK(c, hipMemsetAsync(c->d_sums, 0, sizeof(unsigned long long) * 10 * F, c->stream));
         LAUNCH(c, launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums));
-        HIPCHK(c, hipMemcpyAsync(c->h_sums, c->d_sums, sizeof(unsigned long long) * 10 * F, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, xfer(c, c->h_sums, c->d_sums, sizeof(unsigned long long) * 10 * F, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // sync #3
         for (int f = 0; f < F; ++f) {
             if (!c->h_have[f]) continue;
@@ -488,7 +510,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
             hm::plane_refit_from_moments((const uint64_t*)(c->h_sums + 10 * (size_t)f), in, out);
             c->h_model[f] = make_float4(out[0], out[1], out[2], out[3]);
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
         if (p->plane_model != CD_PLANE) {
             HIPCHK(c, hipStreamSynchronize(c->stream));   // h_active is about to be rewritten
             if (int st = upload_have()) return st;
@@ -657,9 +679,9 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             else if (cl.n < 3) { st.done = 1; st.status = CD_ERR_FEW_CORRESPONDENCES; }
         }
     }
-    HIPCHK(c, hipMemcpyAsync(c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, xfer(c, c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice));
+    HIPCHK(c, xfer(c, c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice));
+    HIPCHK(c, xfer(c, c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
     HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * ((size_t)ncl + 1), c->stream));   // (+ the wave-time word of k_icp_lat)
     if (guess_mode != CD_GUESS_NONE)   // input_transformed = guess * source (d_src is a copy of d_src0 at this point)
@@ -698,7 +720,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         int no = 0;
         for (int k = 0; k < ncl; ++k) if (in_lat[(size_t)k]) c->h_order[no++] = k;
         std::stable_sort(c->h_order, c->h_order + no, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
-        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
         // Shape of the launch (k_icp_lat.hip): clusters per workgroup x waves per cluster.  A call that has the GPU to itself wants
         // the launch short: one cluster per workgroup, four waves each when there are clusters enough to fill the chip that way,
         // eight or sixteen for few or very large clusters (one frame; config 5's thousands of points).  With other batches in
@@ -712,14 +734,16 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         if (busy && n_lat >= 256 && lat_max_n <= 8192) { cpw = 4; wpc = 2; }
         if (c->lat_shape[0] > 0) { cpw = c->lat_shape[0]; wpc = std::max(1, c->lat_shape[1]); per_slot = std::max(1, c->lat_shape[2]); }
         const int n_wg = std::max(1, (n_lat + cpw * per_slot - 1) / (cpw * per_slot));
+        GateHold lat_hold;   // (CUBOID_ICP_CONCURRENT: at most that many contexts between this launch and its completion)
+        if (c->icp_concurrent > 0) lat_hold.enter(&g_icp_gate[c->device & (MAX_DEVICES - 1)], c->icp_concurrent);
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, ip));
         c->timing.icp_kernel_launches = 1;
         c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
-        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
         if (n_lat == n_live) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             float ms1 = 0.f;
             hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -788,8 +812,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
                 ++gq;
             }
         }
-        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
+        HIPCHK(c, xfer(c, c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
         // the LDS-template launch goes to the context's stream (stream3 with icp_lowprio), the global-template launch beside it
         hipStream_t s1 = c->icp_lowprio ? c->stream3 : c->stream;
@@ -817,8 +841,8 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         c->timing.icp_regime = (ipg.pipe_slots << 16) | n_wg;
         if (nwork == 0) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost));
+            HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             float ms1 = 0.f;
             hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -834,14 +858,11 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     if (whole_cluster) {
-        struct GateHold {   // (released on every path out of this block)
-            IcpGate* g = nullptr;
-            ~GateHold() { if (g) g->leave(); }
-        } hold;
-        if (c->icp_concurrent > 0) { hold.g = &g_icp_gate[c->device & (MAX_DEVICES - 1)]; hold.g->enter(c->icp_concurrent); }
+        GateHold hold;   // (released on every path out of this block)
+        if (c->icp_concurrent > 0) hold.enter(&g_icp_gate[c->device & (MAX_DEVICES - 1)], c->icp_concurrent);
         for (int k = 0; k < ncl; ++k) c->h_order[k] = k;
         std::stable_sort(c->h_order, c->h_order + ncl, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
-        HIPCHK(c, hipMemcpyAsync(c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * ncl, hipMemcpyHostToDevice));
         const int wg_cap = c->icp_max_wg > 0 ? std::min(c->icp_max_wg, c->n_cu) : c->n_cu;
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         hipStream_t si = c->icp_lowprio >= 2 ? c->stream3 : c->stream;
@@ -874,9 +895,9 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         }
         HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
         c->timing.icp_kernel_launches = 1;
-        HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
-        if (ip.donate) HIPCHK(c, hipMemcpyAsync(c->h_ctl + 8, c->d_don, sizeof(int) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost));
+        HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
+        if (ip.donate) HIPCHK(c, xfer(c, c->h_ctl + 8, c->d_don, sizeof(int) * 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         float ms1 = 0.f;
         hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -922,15 +943,15 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             int* ctl = c->h_ctl;
             for (int i = 0; i < 8; ++i) ctl[i] = 0;
             ctl[1] = c->icp_persist == 2 ? 1 : 0;
-            HIPCHK(c, hipMemcpyAsync(c->d_queue + 4, ctl, sizeof(int) * 6, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, xfer(c, c->d_queue + 4, ctl, sizeof(int) * 6, hipMemcpyHostToDevice));
             LAUNCH(c, launch_icp_persist(c->stream, nwork, G, max_launch, c->d_work, c->d_cl, c->d_st, c->d_acc, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid,
                                c->d_src, c->d_src0, c->d_nn, c->d_d2, qslice, (unsigned*)(c->d_queue + 4), c->d_queue + 5, n_open, c->d_queue + 6, ip));
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            HIPCHK(c, hipMemcpyAsync(ctl + 8, c->d_queue + 5, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-            HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, xfer(c, ctl + 8, c->d_queue + 5, sizeof(int), hipMemcpyDeviceToHost));
+            HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost));
             c->st_init.assign(c->h_st, c->h_st + 2 * (size_t)ncl);   // in case the launch gives up (no reallocation after the first call)
             std::vector<IcpState>& init = c->st_init;
-            HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
             HIPCHK(c, hipStreamSynchronize(c->stream));
             const int gave_up = ctl[8];
             if (!gave_up) {
@@ -951,7 +972,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: persistent ICP launch gave up at a grid barrier, running the multi-launch loop\n");
             // start over: initial states, zero sums, the source points as extracted (the launch transformed them in place)
             std::memcpy(c->h_st, init.data(), sizeof(IcpState) * 2 * (size_t)ncl);
-            HIPCHK(c, hipMemcpyAsync(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice, c->stream));
+            HIPCHK(c, xfer(c, c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice));
             HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
             HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * (size_t)ncl, c->stream));
             long long span = 0;
@@ -967,12 +988,12 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     // final transform applied, so it needs no further work items (k_icp_solve alone keeps its state).
     int nactive = nwork;
     std::memcpy(c->h_work2, c->h_work, sizeof(IcpWork) * (size_t)std::max(nwork, 1));
-    HIPCHK(c, hipMemcpyAsync(c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)std::max(nwork, 1), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, xfer(c, c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)std::max(nwork, 1), hipMemcpyHostToDevice));
     int group = 8;
     while (nwork > 0 && it < max_launch) {
         const int g = std::min(group, max_launch - it);
         for (int q = 0; q < g; ++q) LAUNCH(c, launch_icp_iter(c->stream, it++, nactive, ncl, c->d_work2, c->d_cl, c->d_st, c->d_acc, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_src, c->d_nn, c->d_d2, qslice, c->d_queue, c->n_cu, ip));
-        HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));
         bool all = true;
         int na = 0;
@@ -984,15 +1005,15 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         if (all) break;
         if (na != nactive) {
             nactive = na;
-            if (na > 0) HIPCHK(c, hipMemcpyAsync(c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)na, hipMemcpyHostToDevice, c->stream));
+            if (na > 0) HIPCHK(c, xfer(c, c->d_work2, c->h_work2, sizeof(IcpWork) * (size_t)na, hipMemcpyHostToDevice));
         }
         group = 16;
     }
     HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
     c->timing.icp_kernel_launches = it;
     LAUNCH(c, launch_icp_fitness(c->stream, nwork, c->d_work, c->d_cl, c->d_st, 0, c->d_accf, c->d_tplk, c->d_tlok, c->d_thik, c->d_grid, c->d_src0, c->d_nn, c->d_d2, qslice));
-    HIPCHK(c, hipMemcpyAsync(c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ncl, hipMemcpyDeviceToHost));
+    HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     float ms = 0.f;
     hipEventElapsedTime(&ms, c->ev[5], c->ev[6]);
@@ -1060,6 +1081,8 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     invalidate_last(c);
     std::memset(&c->timing, 0, sizeof(c->timing));
     BatchGuard in_flight(c->device);
+    GateHold front;
+    if (c->front_concurrent > 0) front.enter(&g_front_gate[c->device & (MAX_DEVICES - 1)], c->front_concurrent);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     int rounds = 0;
     st = stage_crop_voxel(c, d_frames, stride, N, F, p, nullptr);
@@ -1080,6 +1103,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     st = stage_cluster_sync(c, F, p, max_no);   // sync #4: n_plane, n_o, n_k, ksize, koff
     if (st) return st;
     HIPCHK(c, hipEventRecord(c->ev[3], c->stream));
+    front.release();
     // Every cluster of every frame gets its ICP (opd.cpp:376-413).  The device extracts the ICP sources KICP clusters per
     // frame at a time; frames with more than KICP clusters (rare) need further rounds, and the host needs their sizes.
     int kmax = 0, ncl = 0;
@@ -1449,6 +1473,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_DON_IDLE")) c->don_idle = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_DON_FAULT")) c->don_fault = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_ICP_LATTICE")) c->icp_lattice = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_COPY_KERNELS")) c->copy_kernels = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_LAT_SHAPE")) std::sscanf(m, "%d,%d,%d", &c->lat_shape[0], &c->lat_shape[1], &c->lat_shape[2]);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
@@ -1457,6 +1482,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_FORCE_SCAN_STALL")) c->force_stall = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_RUNS")) c->crop_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_CONCURRENT")) c->icp_concurrent = std::max(0, std::atoi(m));
+    if (const char* m = std::getenv("CUBOID_FRONT_CONCURRENT")) c->front_concurrent = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_ICP_MODE")) c->icp_mode = !std::strcmp(m, "sliced") ? 1 : (!std::strcmp(m, "cluster") ? 2 : (!std::strcmp(m, "pipe") ? 3 : 0));
     ok = ok && dalloc(&c->d_work, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work, (size_t)c->work_cap) == hipSuccess;
     ok = ok && dalloc(&c->d_work2, (size_t)c->work_cap) == hipSuccess && halloc(&c->h_work2, (size_t)c->work_cap) == hipSuccess;
@@ -1950,7 +1976,7 @@ static int load_as(cd_context* c, const void* xyz, size_t stride, int n, float4*
         for (int a = 0; a < 3; ++a) if (v[a] < mn[a]) mn[a] = v[a];
     }
     for (int a = 0; a < 3; ++a) c->h_fs[0].origin[a] = n > 0 ? mn[a] : 0.f;
-    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice));
     return CD_OK;
 }
 
@@ -2113,7 +2139,7 @@ static int cd_extract_impl(cd_context* c, const void* points, size_t stride, int
     if (negative) {
         if (n_indices > c->N) return fail(c, CD_ERR_CAPACITY, "index list longer than the context capacity");
         std::memset(&c->h_fs[0], 0, sizeof(FrameState));
-        HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice));
         HIPCHK(c, hipMemsetAsync(c->d_rank, 0, sizeof(int) * (size_t)n, c->stream));            // marks
         HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)c->T, c->stream));          // chained-scan state
         HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
@@ -2156,7 +2182,7 @@ static int cd_passthrough_impl(cd_context* c, const void* points, size_t stride,
     if (st) return st;
     HIPCHK(c, hipMemcpyAsync(c->d_in, points, (size_t)n * stride, hipMemcpyHostToDevice, c->stream));
     std::memset(&c->h_fs[0], 0, sizeof(FrameState));
-    HIPCHK(c, hipMemcpyAsync(c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState), hipMemcpyHostToDevice));
     HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)c->T, c->stream));          // chained-scan state
     HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int), c->stream));
     LAUNCH(c, launch_passthrough_mark(c->stream, c->d_in, stride, n, field < 0 ? -1 : 4 * field, lo, hi, negative ? 1 : 0, c->d_rank));

@@ -36,6 +36,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_build(const float4* __restric
                                                          int* __restrict__ head, int* __restrict__ next,
                                                          int* __restrict__ parent, int* __restrict__ csize,
                                                          int* __restrict__ rank_of_root) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
     if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
@@ -90,6 +91,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
                                                         const FrameState* __restrict__ fs, float inv_cell, float r2,
                                                         const int* __restrict__ head, const int* __restrict__ next,
                                                         int* parent) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
     if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
@@ -131,6 +133,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_hook(const float4* __restrict
 
 __global__ void __launch_bounds__(BLOCK) k_cluster_flatten(int N, const FrameState* __restrict__ fs,
                                                            int* __restrict__ parent, int* __restrict__ csize) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.y;
     const int n = fs[f].n_o;
     if (n <= 0 || fs[f].cl_done) return;      // finished by k_cluster_lds
@@ -261,6 +264,7 @@ __device__ __forceinline__ void cl_join(const int* s_key, const int* s_val, int*
 __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __restrict__ obj, int N, FrameState* __restrict__ fs,
                                                             float inv_cell, float r2, int* __restrict__ parent,
                                                             int* __restrict__ csize, int* __restrict__ rank_of_root) {
+    CD_FRONT_PRIO();
     __shared__ float s_x[CL_LDS_CAP], s_y[CL_LDS_CAP], s_z[CL_LDS_CAP];   // 96 KiB, cell order (s_x / s_y: per-component min / size at the end)
     __shared__ int s_key[CL_SLOTS];                                       // packed cell of the slot, -1 = empty
     __shared__ int s_val[CL_SLOTS + 1];                                   // points in the slot's cell, then their start
@@ -405,6 +409,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __res
                                                         int max_sz, const int* __restrict__ parent,
                                                         const int* __restrict__ csize, int* __restrict__ cand,
                                                         int* __restrict__ rank_of_root, int* __restrict__ sizes_sorted) {
+    CD_FRONT_PRIO();
     __shared__ int s_w[WAVES_PER_BLOCK];
     const int f = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_o;
@@ -465,6 +470,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __res
 __global__ void __launch_bounds__(BLOCK) k_label_count(int N, int T, const FrameState* __restrict__ fs, int enable,
                                                        const int* __restrict__ parent, const int* __restrict__ rank_of_root,
                                                        int* __restrict__ label, int* __restrict__ tile_cnt, int kbase) {
+    CD_FRONT_PRIO();
     __shared__ int s_c[WAVES_PER_BLOCK][KICP];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_o;
@@ -512,6 +518,7 @@ __global__ void __launch_bounds__(BLOCK) k_label_scatter(const float4* __restric
                                                          const FrameState* __restrict__ fs, const int* __restrict__ label,
                                                          const int* __restrict__ tile_off, float4* __restrict__ src0,
                                                          float4* __restrict__ src, int kbase, const int* __restrict__ koff_tab) {
+    CD_FRONT_PRIO();
     __shared__ int s_c[WAVES_PER_BLOCK][KICP];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_o;

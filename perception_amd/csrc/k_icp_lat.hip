@@ -246,6 +246,17 @@ extern "C" int cd_debug_lat_stats(unsigned long long* out, int reset) {
 #define LAT_T(k)
 #endif
 
+// Rule C4's fixed-point term rint(v * 2^shift) WITHOUT taking it out of the double: u = fma(v, 2^shift, 1.5 * 2^52) is exact
+// in its product and rounds once (nearest even) in its sum, and for |v * 2^shift| < 2^50 the BITS of u, read as an integer, are
+// C + rint(v * 2^shift) with C = 0x4338000000000000 (exponent field of [2^52, 2^53), mantissa 2^51 + r).  So a lane adds the raw
+// bits to its 64-bit accumulator - cvt, fma, one 64-bit add: three instructions per term where fixq_fast + add took eight -
+// and since EVERY lane of EVERY pass adds exactly one term to each sum (a lane without a point adds the term of 0, which is C),
+// the solver takes (passes x 64) x C off each sum again (mod 2^64, like the sums themselves).
+constexpr unsigned long long LAT_FIX_C = 0x4338000000000000ull;
+__device__ __forceinline__ unsigned long long lat_fix_bits(float v, double scale) {
+    return (unsigned long long)__double_as_longlong(__fma_rn((double)v, scale, 6755399441055744.0));
+}
+
 struct LatSlot {
     int k, src_off, n, tslot;   // the cluster (index, first point, points, template slot)
     int phase;                  // LAT_ITER / LAT_FIT / LAT_EMPTY
@@ -339,7 +350,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                 const bool moved = s_so[slot].iters > 0;   // X <- T*X from the second iteration on
                 float T[12];
 #pragma unroll
-                for (int i = 0; i < 12; ++i) T[i] = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(s_so[slot].T[i])));   // (uniform: scalar registers)
+                for (int i = 0; i < 12; ++i) T[i] = s_so[slot].T[i];   // (uniform values in vector registers: as scalars they were spilled and re-read lane by lane in every pass)
                 unsigned long long S[16];
 #pragma unroll
                 for (int i = 0; i < 16; ++i) S[i] = 0ull;
@@ -357,31 +368,32 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                         if (act) pts[myq] = make_float4(px, py, pz, p.w);
                     }
                     const LatHit h = nf3 ? lat_nearest<true, 3>(tab, face, F, px, py, pz) : lat_nearest<true, LAT_MAX_FACES>(tab, face, F, px, py, pz);
-                    // float -> fixed point (rule C4) in four instructions per term (fixq_fast, common.hpp), valid while every term stays
-                    // below 2^50 / 2^shift; a wave with a lane outside that range takes the general conversion - same integers either way
-                    const float pv[3] = {px, py, pz}, qv[3] = {h.nx, h.ny, h.nz};
+                    // the 16 moment terms of rule C4, accumulated as the raw bits of fma(v, 2^shift, 1.5 * 2^52) (lat_fix_bits above: the
+                    // solver takes the constants off again).  Valid while every term stays below 2^50 / 2^shift; a wave with a lane
+                    // outside that range (coordinates beyond 256 m, neighbours more than 128 m away) takes the general conversion -
+                    // the same integers either way.  A lane without a point contributes the terms of zero.
+                    const float pv[3] = {act ? px : 0.f, act ? py : 0.f, act ? pz : 0.f}, qv[3] = {act ? h.nx : 0.f, act ? h.ny : 0.f, act ? h.nz : 0.f};
+                    const float dv = act ? h.d : 0.f;
                     const float big_c = fmaxf(fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fabsf(pv[2])), fmaxf(fmaxf(fabsf(qv[0]), fabsf(qv[1])), fabsf(qv[2])));
-                    const bool fast = ballot64(act && !(big_c < 256.f && h.d < 16384.f)) == 0ull;
-                    if (act) {
-                        if (fast) {
+                    const bool fast = ballot64(!(big_c < 256.f && dv < 16384.f)) == 0ull;
+                    if (fast) {
 #pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                S[a] += fixq_fast(pv[a], FIX_SHIFT);
-                                S[3 + a] += fixq_fast(qv[a], FIX_SHIFT);
+                        for (int a = 0; a < 3; ++a) {
+                            S[a] += lat_fix_bits(pv[a], 4294967296.0);
+                            S[3 + a] += lat_fix_bits(qv[a], 4294967296.0);
 #pragma unroll
-                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += fixq_fast(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
-                            }
-                            S[15] += fixq_fast(h.d, FIX_SHIFT_D2);
-                        } else {
-#pragma unroll
-                            for (int a = 0; a < 3; ++a) {
-                                S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT);
-                                S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT);
-#pragma unroll
-                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT);
-                            }
-                            S[15] += (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
+                            for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += lat_fix_bits(__fmul_rn(qv[a], pv[b]), 4294967296.0);
                         }
+                        S[15] += lat_fix_bits(dv, 68719476736.0);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) {
+                            S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT) + LAT_FIX_C;
+                            S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT) + LAT_FIX_C;
+#pragma unroll
+                            for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT) + LAT_FIX_C;
+                        }
+                        S[15] += (unsigned long long)fixq(dv, FIX_SHIFT_D2) + LAT_FIX_C;
                     }
                 }
                 if (sub < npass) wave_fold_to_lds(S, 16, s_acc[slot]);
@@ -411,8 +423,9 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                     float qx, qy, qz;
                     xform(Tf, p0.x, p0.y, p0.z, qx, qy, qz);
                     const LatHit h = nf3 ? lat_nearest<false, 3>(tab, face, F, qx, qy, qz) : lat_nearest<false, LAT_MAX_FACES>(tab, face, F, qx, qy, qz);
-                    const bool fast = ballot64(act && !(h.d < 16384.f)) == 0ull;
-                    if (act) S[0] += fast ? fixq_fast(h.d, FIX_SHIFT_D2) : (unsigned long long)fixq(h.d, FIX_SHIFT_D2);
+                    const float dv = act ? h.d : 0.f;
+                    const bool fast = ballot64(!(dv < 16384.f)) == 0ull;
+                    S[0] += fast ? lat_fix_bits(dv, 68719476736.0) : (unsigned long long)fixq(dv, FIX_SHIFT_D2) + LAT_FIX_C;
                 }
                 if (sub < npass) wave_fold_to_lds(S, 1, s_acc[slot]);
             }
@@ -426,7 +439,10 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
         if (threadIdx.x < CPW) {
             const int s = threadIdx.x;
             LatSlot& sl = s_slot[s];
+            // (every lane of every pass added LAT_FIX_C to each sum it touched: see lat_fix_bits)
+            const unsigned long long off = (unsigned long long)(((sl.n + 63) >> 6) * 64) * LAT_FIX_C;
             if (sl.phase == LAT_ITER && sl.ready) {
+                for (int i = 0; i < 16; ++i) s_acc[s][i] -= off;
                 if (lat_solve(&s_so[s], s_acc[s], sl.n, prm)) sl.phase = LAT_FIT;
                 for (int i = 0; i < 16; ++i) s_acc[s][i] = 0ull;
                 sl.ready = 0;
@@ -435,7 +451,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                 s_so[s].converged = 1;
                 st[2 * (size_t)sl.k] = s_so[s];
                 st[2 * (size_t)sl.k + 1] = s_so[s];
-                accf[sl.k] = s_acc[s][0];
+                accf[sl.k] = s_acc[s][0] - off;
                 refill(s);
                 if (sl.phase != LAT_EMPTY) s_flags[1] = 1;
             }

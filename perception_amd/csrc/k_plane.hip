@@ -13,6 +13,8 @@
 // coefficients are wave-uniform (scalar loads), the inlier test is reduced per hypothesis with
 // a 64-wide ballot + popcount and one atomic per wave.  The host replays PCL's sequential
 // adaptive-k stop rule over the count vector (bit-exact: counts are integers).
+#include <algorithm>
+
 #include "kernels.hpp"
 
 namespace cd {
@@ -22,6 +24,7 @@ __global__ void __launch_bounds__(WAVE) k_ransac_sample(const float4* __restrict
                                                         FrameState* __restrict__ fs, const int* __restrict__ rnd,
                                                         int h_target, const int* __restrict__ active,
                                                         float4* __restrict__ models, int* __restrict__ valid) {
+    CD_FRONT_PRIO();
     __shared__ int s_key[SAMPLER_MAP];
     __shared__ int s_val[SAMPLER_MAP];
     const int f = blockIdx.x;
@@ -94,6 +97,7 @@ __global__ void __launch_bounds__(BLOCK) k_ransac_count(const float4* __restrict
                                                         const float4* __restrict__ models, const int* __restrict__ valid,
                                                         const int* __restrict__ active, int h0, int h1, float thr,
                                                         int* __restrict__ counts) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (active && !active[f]) return;
     const int n = fs[f].n_v;
@@ -133,6 +137,7 @@ __global__ void __launch_bounds__(BLOCK) k_plane_cov(const float4* __restrict__ 
                                                      const FrameState* __restrict__ fs, const float4* __restrict__ model,
                                                      const int* __restrict__ have, float thr,
                                                      unsigned long long* __restrict__ sums) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_v;
     if (tile * TILE >= n || !have[f]) return;
@@ -197,6 +202,7 @@ __global__ void __launch_bounds__(BLOCK) k_plane_flag_count(const float4* __rest
                                                             const float4* __restrict__ model, const int* __restrict__ have,
                                                             float thr, int negative, int crop2, float z2lo, float z2hi, BBoxGate gate,
                                                             int* __restrict__ cnt_plane, int* __restrict__ cnt_obj) {
+    CD_FRONT_PRIO();
     __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_v;
@@ -230,6 +236,7 @@ __global__ void __launch_bounds__(BLOCK) k_extract_scatter(const float4* __restr
                                                            float thr, int negative, int crop2, float z2lo, float z2hi, BBoxGate gate,
                                                            const int* __restrict__ off_plane, const int* __restrict__ off_obj,
                                                            int* __restrict__ plane_idx, float4* __restrict__ obj_out) {
+    CD_FRONT_PRIO();
     __shared__ int s_a[WAVES_PER_BLOCK], s_b[WAVES_PER_BLOCK];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int n = fs[f].n_v;
@@ -296,6 +303,7 @@ void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int 
 // ---- S3 as a call of its own: pcl::ExtractIndices<PCLPointCloud2> on whole records --------------------------------------
 // (the fused path extracts inside k_extract_scatter; these serve cd_extract.)  Records are `words` 4-byte words.
 __global__ void __launch_bounds__(BLOCK) k_mark_indices(const int* __restrict__ idx, int m, int n, int* __restrict__ flag) {
+    CD_FRONT_PRIO();
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i < m) { const int k = idx[i]; if (k >= 0 && k < n) flag[k] = 1; }
 }
@@ -304,6 +312,7 @@ __global__ void __launch_bounds__(BLOCK) k_mark_indices(const int* __restrict__ 
 // PCL's `distance_value > filter_limit_max_ || distance_value < filter_limit_min_` (negative: `<` and `>`)
 __global__ void __launch_bounds__(BLOCK) k_passthrough_mark(const char* __restrict__ in, size_t stride, int n, int field_off, double lo, double hi,
                                                             int negative, int* __restrict__ flag) {
+    CD_FRONT_PRIO();
     const int i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const char* p = in + (size_t)i * stride;
@@ -320,6 +329,7 @@ __global__ void __launch_bounds__(BLOCK) k_passthrough_mark(const char* __restri
 // positions i with flag[i] == 0, ascending (ordered compaction: ballots + chained scan over the tiles)
 __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict__ flag, int n, int* __restrict__ state,
                                                            FrameState* __restrict__ fs, int* __restrict__ out, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_excl, s_ticket;
     const int tile = take_ticket(ticket, (int)gridDim.x, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -355,6 +365,7 @@ __global__ void __launch_bounds__(BLOCK) k_select_unmarked(const int* __restrict
 }
 __global__ void __launch_bounds__(BLOCK) k_gather_records(const uint32_t* __restrict__ in, int words, const int* __restrict__ idx,
                                                           int m, uint32_t* __restrict__ out) {
+    CD_FRONT_PRIO();
     const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (size_t)m * words) return;
     const int r = (int)(t / words), wd = (int)(t % words);
@@ -365,6 +376,7 @@ __global__ void __launch_bounds__(BLOCK) k_gather_records(const uint32_t* __rest
 // pcl::toROSMsg ships the struct as it is), every other word zero.  One thread per output word: coalesced stores.
 __global__ void __launch_bounds__(BLOCK) k_pack_records(const float4* __restrict__ pts, int m, int words, int rgb_word, uint32_t pad3,
                                                         uint32_t* __restrict__ out) {
+    CD_FRONT_PRIO();
     const size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (size_t)m * words) return;
     const int r = (int)(t / words), wd = (int)(t % words);
@@ -380,6 +392,23 @@ __global__ void __launch_bounds__(BLOCK) k_pack_records(const float4* __restrict
 void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int rgb_word, uint32_t pad3, void* out) {
     const size_t tot = (size_t)m * words;
     if (tot > 0) hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((tot + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, s, pts, m, words, rgb_word, pad3, (uint32_t*)out);
+}
+// Small transfers between the context's PINNED host mirrors (device-visible) and device memory as ordinary kernels of the
+// context's stream instead of hipMemcpyAsync.  Why: the runtime hands such copies to an SDMA engine, where a copy waits IN THE
+// ENGINE'S RING for the kernel before it on its stream - with batches in flight that kernel may be queued for milliseconds
+// behind other contexts' ICP launches, and every other context's copy on the same engine waits behind it (measured:
+// hipMemcpyAsync calls of ALL contexts blocking 5-8 ms at once, tools/hip_api_long_calls.sh).  A kernel is ordered by its own
+// stream only.  Rows of `width` bytes (a multiple of 4), `rows` of them, pitches in bytes; rows = 1 for a plain copy.
+__global__ void __launch_bounds__(BLOCK) k_copy_rows(uint32_t* __restrict__ dst, size_t dpitch_w, const uint32_t* __restrict__ src, size_t spitch_w,
+                                                     int width_w, int rows) {
+    for (int r = blockIdx.y; r < rows; r += gridDim.y)
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < width_w; i += gridDim.x * BLOCK) dst[(size_t)r * dpitch_w + i] = src[(size_t)r * spitch_w + i];
+}
+void launch_copy_rows(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows) {
+    if (width == 0 || rows <= 0) return;
+    const int width_w = (int)(width / 4);
+    const int gx = std::min(64, (width_w + BLOCK - 1) / BLOCK), gy = std::min(rows, 1024);
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, gy), dim3(BLOCK), 0, s, (uint32_t*)dst, dpitch / 4, (const uint32_t*)src, spitch / 4, width_w, rows);
 }
 void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag) {
     if (n > 0) hipLaunchKernelGGL(k_passthrough_mark, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, (const char*)in, stride, n, field_off, lo, hi, negative, flag);

@@ -59,6 +59,7 @@ constexpr int GHIST_TILES = 4;   // sort tiles per workgroup of the histogram ke
 __global__ void __launch_bounds__(SORT_BLOCK) k_radix_ghist(const uint32_t* __restrict__ kin, int N, int npass,
                                                             const FrameState* __restrict__ fs, uint32_t* __restrict__ ghist,
                                                             KeyPack kp) {
+    CD_FRONT_PRIO();
     __shared__ uint32_t s_h[SORT_MAX_PASSES][RADIX];
     const int f = blockIdx.y, lane = threadIdx.x & 63;
     const int n = fs[f].n_c;
@@ -99,6 +100,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
                                                          int T, int Tact, int pass, int shift, FrameState* __restrict__ fs,
                                                          const uint32_t* __restrict__ ghist, int* __restrict__ state,
                                                          KeyPack kp, int use_runs, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_ticket;
     __shared__ unsigned short s_wh[SORT_WAVES][RADIX];   // per-wave bin counts, then the wave's offset inside the bin
     __shared__ uint32_t s_goff[RADIX];                   // where the tile's part of each bin starts in the frame
@@ -253,6 +255,7 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_voxel_runs(const uint32_t* __res
                                                            FrameState* __restrict__ fs, uint32_t* __restrict__ ghist,
                                                            int* __restrict__ state, uint32_t* __restrict__ kout,
                                                            uint32_t* __restrict__ vout, KeyPack kp, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ uint32_t s_h[SORT_MAX_PASSES][RADIX];
     __shared__ int s_cnt[SORT_WAVES];
     __shared__ int s_out0, s_ticket;

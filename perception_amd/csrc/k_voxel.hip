@@ -50,6 +50,7 @@ __device__ __forceinline__ bool crop_keep(float x, float y, float z, const CropL
 __global__ void __launch_bounds__(BLOCK) k_crop_count(const char* __restrict__ in, size_t stride, int N, int rgb_off,
                                                       CropLimits lim, int T, FrameState* __restrict__ fs,
                                                       int* __restrict__ tile_cnt) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -107,6 +108,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_count(const char* __restrict__ i
 // counts[row*T + t] -> exclusive prefix in place; total -> totals[row*total_pitch].
 __global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, int T, int* __restrict__ totals,
                                                       int total_pitch) {
+    CD_FRONT_PRIO();
     __shared__ int s_w[WAVES_PER_BLOCK];
     __shared__ int s_base;
     const int row = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, 
 // after k_crop_runs: digit d of the packed cell keys varies in a frame when its histogram has two non-empty bins.  One wave per
 // frame, four coalesced 256-byte reads per digit.
 __global__ void __launch_bounds__(WAVE) k_digit_vary(FrameState* __restrict__ fs, const uint32_t* __restrict__ ghist) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.x, lane = threadIdx.x;
     int vary = 0;
     for (int d = 0; d < 4; ++d) {
@@ -149,6 +152,7 @@ __global__ void __launch_bounds__(WAVE) k_digit_vary(FrameState* __restrict__ fs
     if (lane == 0) fs[f].digit_vary = vary;
 }
 __global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
+    CD_FRONT_PRIO();
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= F) return;
     FrameState& s = fs[f];
@@ -186,6 +190,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_compact(const char* __restrict__
                                                         const FrameState* __restrict__ fs,
                                                         const int* __restrict__ tile_off, float4* __restrict__ cpt,
                                                         uint32_t* __restrict__ keys) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     const int f = blockIdx.y, tile = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     if (fs[f].n_c <= 0) return;
@@ -236,6 +241,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
                                                       FrameState* __restrict__ fs, int* __restrict__ state,
                                                       float4* __restrict__ cpt,
                                                       uint32_t* __restrict__ keys, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
     __shared__ int s_excl, s_ticket;
@@ -347,6 +353,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
                                                      FrameState* __restrict__ fs, unsigned long long* __restrict__ state,
                                                      float4* __restrict__ cpt, uint32_t* __restrict__ rkeys, uint32_t* __restrict__ rvals,
                                                      uint32_t* __restrict__ ghist, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK], s_rcnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
     __shared__ uint32_t s_h[4][RADIX];
@@ -525,6 +532,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid(const uint32_t* __rest
                                                           const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
                                                           FrameState* __restrict__ fs, int* __restrict__ state,
                                                           float4* __restrict__ vox, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];     // sorted positions of the voxel heads of this tile, in order
     __shared__ int s_out0, s_ticket;
@@ -610,6 +618,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                                                                const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
                                                                FrameState* __restrict__ fs, int* __restrict__ state,
                                                                float4* __restrict__ vox, int* __restrict__ ticket) {
+    CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];
     __shared__ int s_out0, s_ticket;
