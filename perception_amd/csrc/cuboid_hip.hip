@@ -34,7 +34,8 @@ struct cd_context {
     FrameState* d_fs = nullptr;
     FrameState* h_fs = nullptr;
     // ordered-compaction tile counters
-    int *d_tileA = nullptr, *d_tileB = nullptr, *d_tileK = nullptr;
+    int *d_tileA = nullptr, *d_tileB = nullptr, *d_tileK = nullptr, *d_tileC = nullptr;   // (tileC: the centroid kernel's scan state - its own array, so that one launch can zero every array of a batch up front)
+    bool batch_zeroed = false;      // a fused batch call has zeroed the scratch arrays of all its stages in one launch (zero_batch_arrays): the stages skip their own fills
     bool crop_two_pass = false;   // CUBOID_CROP_TWO_PASS=1: always the two-pass crop
     int icp_persist = 1;          // CUBOID_ICP_PERSIST=0: the sliced driver always in its multi-launch form; 2: the persistent
                                   // launch starts with its abort flag raised (tests the hand-over to the multi-launch form)
@@ -92,6 +93,7 @@ struct cd_context {
     IcpLattice* d_lat = nullptr;                                  // per template slot: axis tables and faces of a lattice template (nface = 0: none)
     int tpl_faces[CD_MAX_TEMPLATES] = {0};                        // faces of the slot's lattice (0: the generic searches take it)
     int icp_lattice = 1;                                          // CUBOID_ICP_LATTICE=0: lattice templates take the generic searches too (A/B, fallback tests)
+    int zero_once = 1;                                            // CUBOID_ZERO_ONCE=0: every stage of a fused batch call fills its scratch arrays itself (A/B)
     int copy_kernels = 1;                                         // CUBOID_COPY_KERNELS=0: the small pinned <-> device transfers go through hipMemcpyAsync (SDMA) again
     int lat_shape[3] = {0, 0, 0};                                 // CUBOID_LAT_SHAPE=cpw,wpc[,per_slot]: clusters per workgroup, waves per cluster, clusters per slot of k_icp_lat (0: by regime)
     hipStream_t stream2 = nullptr, stream3 = nullptr;             // streams of the persistent ICP launches: the second launch of a mixed-template batch runs beside the
@@ -264,6 +266,12 @@ static hipError_t xfer2d(cd_context* c, void* dst, size_t dpitch, const void* sr
     return hipGetLastError();
 }
 
+// a stage's zero-fill of one of its scratch arrays - skipped when the fused batch call has zeroed them all in one launch
+#define ZERO_FILL(ctx, ptr, bytes)                                                            \
+    do {                                                                                      \
+        if (!(ctx)->batch_zeroed) HIPCHK(ctx, hipMemsetAsync((ptr), 0, (bytes), (ctx)->stream)); \
+    } while (0)
+
 int ensure_input(cd_context* c, size_t bytes) {
     if (bytes <= c->d_in_bytes) return CD_OK;
     if (c->d_in) hipFree(c->d_in);
@@ -281,6 +289,7 @@ int ensure_clusters(cd_context* c, int ncl, long long points) {
     if (ncl <= c->cl_cap && work_need <= c->work_cap) return CD_OK;
     if (work_need > 0x7fffffffll) return fail(c, CD_ERR_CAPACITY, "ICP work list exceeds 2^31 items");
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->batch_zeroed = false;   // (new arrays: stage_icp fills them itself)
     void* dev[] = {c->d_cl, c->d_order, c->d_work, c->d_work2, c->d_st, c->d_acc, c->d_accf};
     for (void* p : dev) if (p) hipFree(p);
     void* host[] = {c->h_cl, c->h_order, c->h_work, c->h_work2, c->h_st, c->h_accf};
@@ -359,13 +368,15 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     int st = CD_OK;
     // (the ticket counters reset themselves at the end of every launch that uses them; zeroed here too so that a call that
     // failed half way can never leave the next one with a counter that is not zero)
-    HIPCHK(c, hipMemsetAsync(c->d_ticket, 0, sizeof(int) * (size_t)F * TICKET_PITCH, c->stream));
+    ZERO_FILL(c, c->d_ticket, sizeof(int) * (size_t)F * TICKET_PITCH);
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice));
-        HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+        // (the rare redo, and the crops that use d_tileA themselves: from here on every stage fills its own arrays again)
+        if (attempt > 0 || !(kp.enabled && crop_runs)) c->batch_zeroed = false;
+        ZERO_FILL(c, c->d_tileA, sizeof(int) * (size_t)F * T);
         if (kp.enabled && crop_runs) {
-            HIPCHK(c, hipMemsetAsync(c->d_tile64, 0, sizeof(unsigned long long) * (size_t)F * T, c->stream));
-            HIPCHK(c, hipMemsetAsync(c->d_ghist, 0, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX, c->stream));
+            ZERO_FILL(c, c->d_tile64, sizeof(unsigned long long) * (size_t)F * T);
+            ZERO_FILL(c, c->d_ghist, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX);
             LAUNCH(c, launch_crop_runs(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tile64, c->d_cpt, c->d_key[0], c->d_val[0],
                              c->d_ghist, c->d_ticket));
             LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, c->d_ghist));
@@ -423,11 +434,11 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     const uint32_t* vin = c->d_val[cur];   // zero passes (empty frames only): the permutation is never read
     // voxel heads + centroids in one kernel: n_v (0 from the FrameState init for empty frames) and every tile's output
     // offset come from a chained scan (state in d_tileA)
-    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
+    ZERO_FILL(c, c->d_tileC, sizeof(int) * (size_t)F * T);
     if (crop_runs || by_runs)
-        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, crop_runs ? Tc_runs : Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
+        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, crop_runs ? Tc_runs : Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileC, c->d_vox, c->d_ticket));
     else
-        LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileA, c->d_vox, c->d_ticket));
+        LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileC, c->d_vox, c->d_ticket));
     if (rounds_out) *rounds_out = 0;
     return CD_OK;
 }
@@ -443,7 +454,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     std::vector<hm::RansacReplay> rep(F);
     iterations.assign(F, 0);
     for (int f = 0; f < F; ++f) c->h_active[f] = (c->h_fs[f].status == CD_OK || c->h_fs[f].status == CD_ERR_NO_MODEL) ? 1 : 0;
-    HIPCHK(c, hipMemsetAsync(c->d_counts, 0, sizeof(int) * (size_t)F * MAX_HYP, c->stream));
+    ZERO_FILL(c, c->d_counts, sizeof(int) * (size_t)F * MAX_HYP);
     const int targets[4] = {16, 64, 256, MAX_HYP};
     const int h_cap = std::min(MAX_HYP, p->plane_max_iterations + 40);   // max_iterations+1 plus 39 skipped models
     int h_prev = 0, rounds = 0;
@@ -500,7 +511,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
     if (int st = upload_have()) return st;
     if (p->plane_optimize) {
-        HIPCHK(c, hipMemsetAsync(c->d_sums, 0, sizeof(unsigned long long) * 10 * F, c->stream));
+        ZERO_FILL(c, c->d_sums, sizeof(unsigned long long) * 10 * F);
         LAUNCH(c, launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums));
         HIPCHK(c, xfer(c, c->h_sums, c->d_sums, sizeof(unsigned long long) * 10 * F, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // sync #3
@@ -533,8 +544,8 @@ int stage_extract(cd_context* c, int F, const cd_params* p, int gate_mode = -1) 
     gate.enable = gate_mode >= 0 ? gate_mode : (p->bbox_enable ? 1 : 0);
     for (int i = 0; i < 12; ++i) gate.P[i] = p->bbox_P[i];
     for (int i = 0; i < 4; ++i) gate.rect[i] = (float)p->bbox_rect[i];
-    HIPCHK(c, hipMemsetAsync(c->d_tileA, 0, sizeof(int) * (size_t)F * T, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_tileB, 0, sizeof(int) * (size_t)F * T, c->stream));
+    ZERO_FILL(c, c->d_tileA, sizeof(int) * (size_t)F * T);
+    ZERO_FILL(c, c->d_tileB, sizeof(int) * (size_t)F * T);
     LAUNCH(c, launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB));
     LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_plane), FS_PITCH));
     LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileB, F, T, FS_FIELD(c, n_o), FS_PITCH));
@@ -563,7 +574,7 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint, boo
         LAUNCH(c, launch_cluster_flatten(c->stream, c->N, F, To, c->d_fs, c->d_parent, c->d_csize));
     }
     LAUNCH(c, launch_cluster_rank(c->stream, c->N, F, c->d_fs, p->cluster_enable, p->cluster_min_size, p->cluster_max_size, c->d_parent, c->d_csize, c->d_cand, c->d_rank, c->d_sizes));
-    HIPCHK(c, hipMemsetAsync(c->d_tileK, 0, sizeof(int) * (size_t)F * KICP * T, c->stream));
+    ZERO_FILL(c, c->d_tileK, sizeof(int) * (size_t)F * KICP * T);
     LAUNCH(c, launch_label_count(c->stream, c->N, F, T, To, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK, 0));
     LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileK, F * KICP, T, nullptr, 0));
     LAUNCH(c, launch_label_scatter(c->stream, c->d_obj, c->N, F, T, To, c->d_fs, c->d_label, c->d_tileK, c->d_src0, c->d_src, 0, nullptr));
@@ -581,6 +592,7 @@ int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
     for (int f = 0; f < F; ++f) left = left || (c->h_fs[f].n_o > 0 && !c->h_fs[f].cl_done);
     if (!left) return CD_OK;
     if (std::getenv("CUBOID_DEBUG")) std::fprintf(stderr, "cuboid_hip: LDS clustering gave frames up, running the global-memory path\n");
+    c->batch_zeroed = false;   // (d_tileK has been used: the redo fills it again)
     st = stage_cluster(c, F, p, max_no, true);
     if (st) return st;
     return sync_fs(c, F);
@@ -682,8 +694,13 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
     HIPCHK(c, xfer(c, c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice));
     HIPCHK(c, xfer(c, c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice));
     HIPCHK(c, xfer(c, c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice));
-    HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
-    HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * ((size_t)ncl + 1), c->stream));   // (+ the wave-time word of k_icp_lat)
+    // (zeroed up front by the fused call for its FIRST ICP stage only: a batch that runs one stage per template fills them again)
+    const bool pre_zeroed = c->batch_zeroed;
+    c->batch_zeroed = false;
+    if (!pre_zeroed) {
+        HIPCHK(c, hipMemsetAsync(c->d_acc, 0, sizeof(unsigned long long) * 48 * (size_t)ncl, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->d_accf, 0, sizeof(unsigned long long) * ((size_t)ncl + 1), c->stream));   // (+ the wave-time word of k_icp_lat)
+    }
     if (guess_mode != CD_GUESS_NONE)   // input_transformed = guess * source (d_src is a copy of d_src0 at this point)
         LAUNCH(c, launch_icp_apply_guess(c->stream, ncl, max_n, c->d_cl, c->d_guess, guess_mode == CD_GUESS_PER_FRAME ? 1 : 0, c->d_src0, c->d_src));
     IcpParams ip;
@@ -736,7 +753,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         const int n_wg = std::max(1, (n_lat + cpw * per_slot - 1) / (cpw * per_slot));
         GateHold lat_hold;   // (CUBOID_ICP_CONCURRENT: at most that many contexts between this launch and its completion)
         if (c->icp_concurrent > 0) lat_hold.enter(&g_icp_gate[c->device & (MAX_DEVICES - 1)], c->icp_concurrent);
-        HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
+        if (!pre_zeroed) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
         LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, ip));
         c->timing.icp_kernel_launches = 1;
         c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
@@ -1084,6 +1101,32 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     GateHold front;
     if (c->front_concurrent > 0) front.enter(&g_front_gate[c->device & (MAX_DEVICES - 1)], c->front_concurrent);
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
+    struct ZeroedScope {   // the stages skip their own fills for the duration of this call only
+        cd_context* c;
+        ~ZeroedScope() { c->batch_zeroed = false; }
+    } zeroed_scope{c};
+    if (c->zero_once) {
+        // every scratch array the stages want zeroed, in ONE launch (a batch had ~14 fill kernels, each a stream operation of its
+        // own that queues behind the other contexts' kernels)
+        ZeroRegions zr;
+        zr.n = 0;
+        auto add = [&](void* ptr, size_t bytes) { zr.ptr[zr.n] = (uint32_t*)ptr; zr.words[zr.n] = bytes / 4; ++zr.n; };
+        const size_t FT = (size_t)F * c->T;
+        add(c->d_ticket, sizeof(int) * (size_t)F * TICKET_PITCH);
+        add(c->d_tileA, sizeof(int) * FT);
+        add(c->d_tileB, sizeof(int) * FT);
+        add(c->d_tileC, sizeof(int) * FT);
+        add(c->d_tile64, sizeof(unsigned long long) * FT);
+        add(c->d_ghist, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX);
+        add(c->d_counts, sizeof(int) * (size_t)F * MAX_HYP);
+        add(c->d_sums, sizeof(unsigned long long) * 10 * (size_t)F);
+        add(c->d_tileK, sizeof(int) * FT * KICP);
+        add(c->d_acc, sizeof(unsigned long long) * 48 * (size_t)c->cl_cap);
+        add(c->d_accf, sizeof(unsigned long long) * ((size_t)c->cl_cap + 1));
+        add(c->d_queue, sizeof(int) * 16);
+        LAUNCH(c, launch_zero_regions(c->stream, zr));
+        c->batch_zeroed = true;
+    }
     int rounds = 0;
     st = stage_crop_voxel(c, d_frames, stride, N, F, p, nullptr);
     if (st) return st;
@@ -1393,6 +1436,7 @@ void cd_destroy(cd_context* c) {
     if (c->d_guess) hipFree(c->d_guess);
     if (c->d_super) hipFree(c->d_super);
     if (c->d_lat) hipFree(c->d_lat);
+    if (c->d_tileC) hipFree(c->d_tileC);
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->stream3) { hipStreamSynchronize(c->stream3); hipStreamDestroy(c->stream3); }
     for (auto& e : c->ev2) if (e) hipEventDestroy(e);
@@ -1423,7 +1467,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     bool ok = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, 0) == hipSuccess;
     for (auto& e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && dalloc(&c->d_fs, F) == hipSuccess && halloc(&c->h_fs, F) == hipSuccess;
-    ok = ok && dalloc(&c->d_tileA, F * T) == hipSuccess && dalloc(&c->d_tileB, F * T) == hipSuccess && dalloc(&c->d_tileK, F * KICP * T) == hipSuccess;
+    ok = ok && dalloc(&c->d_tileA, F * T) == hipSuccess && dalloc(&c->d_tileB, F * T) == hipSuccess && dalloc(&c->d_tileK, F * KICP * T) == hipSuccess && dalloc(&c->d_tileC, F * T) == hipSuccess;
     ok = ok && dalloc(&c->d_cpt, FN) == hipSuccess && dalloc(&c->d_vox, FN) == hipSuccess && dalloc(&c->d_obj, FN) == hipSuccess;
     ok = ok && dalloc(&c->d_src0, FN) == hipSuccess && dalloc(&c->d_src, FN) == hipSuccess;
     for (int k = 0; k < 2; ++k) ok = ok && dalloc(&c->d_key[k], FN) == hipSuccess && dalloc(&c->d_val[k], FN) == hipSuccess;
@@ -1474,6 +1518,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ICP_DON_FAULT")) c->don_fault = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_ICP_LATTICE")) c->icp_lattice = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_COPY_KERNELS")) c->copy_kernels = std::atoi(m);
+    if (const char* m = std::getenv("CUBOID_ZERO_ONCE")) c->zero_once = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_LAT_SHAPE")) std::sscanf(m, "%d,%d,%d", &c->lat_shape[0], &c->lat_shape[1], &c->lat_shape[2]);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));

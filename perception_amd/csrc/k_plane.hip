@@ -404,6 +404,15 @@ __global__ void __launch_bounds__(BLOCK) k_copy_rows(uint32_t* __restrict__ dst,
     for (int r = blockIdx.y; r < rows; r += gridDim.y)
         for (int i = blockIdx.x * BLOCK + threadIdx.x; i < width_w; i += gridDim.x * BLOCK) dst[(size_t)r * dpitch_w + i] = src[(size_t)r * spitch_w + i];
 }
+// every zero-initialised scratch array of a fused batch call in ONE launch (blockIdx.y = region) instead of a dozen fill kernels
+__global__ void __launch_bounds__(BLOCK) k_zero_regions(ZeroRegions r) {
+    uint32_t* p = r.ptr[blockIdx.y];
+    const size_t n = r.words[blockIdx.y];
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) p[i] = 0u;
+}
+void launch_zero_regions(hipStream_t s, const ZeroRegions& r) {
+    if (r.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(128, r.n), dim3(BLOCK), 0, s, r);
+}
 void launch_copy_rows(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows) {
     if (width == 0 || rows <= 0) return;
     const int width_w = (int)(width / 4);

@@ -22,6 +22,8 @@ void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint3
                                 int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
+struct ZeroRegions { int n; uint32_t* ptr[16]; size_t words[16]; };
+void launch_zero_regions(hipStream_t s, const ZeroRegions& r);
 void launch_copy_rows(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows);
 void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag);
 void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out, int* ticket);
