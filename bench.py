@@ -512,8 +512,8 @@ def main():
                               "frame's other clusters start from the same matrix") +
                              "; the guesses are computed before this leg's timed region"}
 
-    # Self-check of the timed path, outside the timed region: the records of the LAST timed step (k_icp_pipe with refilled
-    # slots, other batches in flight, gathered over all ranks) must be byte-identical to a strictly serial pass of this
+    # Self-check of the timed path, outside the timed region: the records of the LAST timed step (the in-flight launch shape of
+    # the ICP kernel with refilled slots, other batches in flight, gathered over all ranks) must be byte-identical to a strictly serial pass of this
     # rank's batch on an otherwise idle GPU.
     verified = None
     serial_rec = None
@@ -869,7 +869,7 @@ def main():
             "generic_search": legs_out.get("generic_search"), "object_launch": legs_out.get("object_launch"),
             "cu_fill_debug": cu_fill,
             "verified": verified,
-            "verified_note": "records of the last timed step (batches in flight, k_icp_pipe with refilled slots, gathered) are "
+            "verified_note": "records of the last timed step (batches in flight, the ICP kernel in its in-flight launch shape with refilled slots, gathered) are "
                              "byte-identical to a strictly serial pass run after the timed region",
             "icp": {"clusters": ncl, "accepted": int(acc), "mean_iterations": float(np.mean(iters)) if iters else 0.0,
                     "max_iterations": int(max(iters)) if iters else 0, "frames": nfr},

@@ -272,6 +272,27 @@ static hipError_t xfer2d(cd_context* c, void* dst, size_t dpitch, const void* sr
         if (!(ctx)->batch_zeroed) HIPCHK(ctx, hipMemsetAsync((ptr), 0, (bytes), (ctx)->stream)); \
     } while (0)
 
+// consecutive small transfers of a stage collected into one launch (xfer's fallback applies: without copy kernels, or for a
+// width that is no multiple of 4, each goes through the runtime's copy as before)
+struct XferBatch {
+    cd_context* c;
+    CopyList L;
+    hipError_t err = hipSuccess;
+    explicit XferBatch(cd_context* ctx) : c(ctx) { L.n = 0; }
+    void add2d(void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows, hipMemcpyKind kind) {
+        if (err != hipSuccess || width == 0 || rows <= 0) return;
+        if (!c->copy_kernels || (width & 3) || (dpitch & 3) || (spitch & 3)) { err = hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, kind, c->stream); return; }
+        if (L.n == 8) flush();
+        L.seg[L.n++] = CopySeg{(uint32_t*)dst, (const uint32_t*)src, dpitch / 4, spitch / 4, (int)(width / 4), rows};
+    }
+    void add(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) { add2d(dst, bytes, src, bytes, bytes, 1, kind); }
+    hipError_t flush() {
+        if (L.n > 0 && err == hipSuccess) { launch_copy_list(c->stream, L); err = hipGetLastError(); }
+        L.n = 0;
+        return err;
+    }
+};
+
 int ensure_input(cd_context* c, size_t bytes) {
     if (bytes <= c->d_in_bytes) return CD_OK;
     if (c->d_in) hipFree(c->d_in);
@@ -310,8 +331,8 @@ int ensure_clusters(cd_context* c, int ncl, long long points) {
     return CD_OK;
 }
 
-int sync_fs(cd_context* c, int F) {
-    HIPCHK(c, xfer(c, c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost));
+int sync_fs(cd_context* c, int F, bool copied = false) {   // copied: the caller has put the FrameState read-back on the stream already
+    if (!copied) HIPCHK(c, xfer(c, c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     for (int f = 0; f < F; ++f)
         if (c->h_fs[f].scan_stalled) return fail(c, CD_INTERNAL_STALL, "a chained scan stalled (workgroups of a grid were not started in id order)");
@@ -465,10 +486,15 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
         LAUNCH(c, launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, c->d_active, c->d_models, c->d_valid));
         LAUNCH(c, launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, c->d_active, h_prev, h_target, thr, c->d_counts));
         // only the first h_target columns of the [F][MAX_HYP] tables are live: one strided copy each
-        HIPCHK(c, xfer2d(c, c->h_counts, sizeof(int) * MAX_HYP, c->d_counts, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost));
-        HIPCHK(c, xfer2d(c, c->h_valid, sizeof(int) * MAX_HYP, c->d_valid, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost));
-        HIPCHK(c, xfer2d(c, c->h_models, sizeof(float4) * MAX_HYP, c->d_models, sizeof(float4) * MAX_HYP, sizeof(float4) * h_target, F, hipMemcpyDeviceToHost));
-        int st = sync_fs(c, F);   // sync #2 (per round): counts + n_hyp
+        {   // (one launch: the three tables and - sync_fs below finds it done - nothing else; the FrameState read-back follows)
+            XferBatch xb(c);
+            xb.add2d(c->h_counts, sizeof(int) * MAX_HYP, c->d_counts, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost);
+            xb.add2d(c->h_valid, sizeof(int) * MAX_HYP, c->d_valid, sizeof(int) * MAX_HYP, sizeof(int) * h_target, F, hipMemcpyDeviceToHost);
+            xb.add2d(c->h_models, sizeof(float4) * MAX_HYP, c->d_models, sizeof(float4) * MAX_HYP, sizeof(float4) * h_target, F, hipMemcpyDeviceToHost);
+            xb.add(c->h_fs, c->d_fs, sizeof(FrameState) * F, hipMemcpyDeviceToHost);
+            HIPCHK(c, xb.flush());
+        }
+        int st = sync_fs(c, F, /*copied=*/true);   // sync #2 (per round): counts + n_hyp
         if (st) return st;
         ++rounds;
         bool all_done = true;
@@ -500,16 +526,18 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     }
     // selectWithinDistance of a constrained model returns nothing when the model violates the constraint: the
     // device then sees "no model" (h_active doubles as the pinned staging copy), the host keeps reporting it
-    auto upload_have = [&]() -> int {
+    auto upload_have = [&](const float4* models_too = nullptr) -> int {
         for (int f = 0; f < F; ++f) {
             const float mm[4] = {c->h_model[f].x, c->h_model[f].y, c->h_model[f].z, c->h_model[f].w};
             c->h_active[f] = c->h_have[f] && hm::plane_model_valid(p->plane_model, mm, p->plane_axis, p->plane_eps_angle) ? 1 : 0;
         }
-        HIPCHK(c, xfer(c, c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice));
+        XferBatch xb(c);
+        if (models_too) xb.add(c->d_model, models_too, sizeof(float4) * F, hipMemcpyHostToDevice);
+        xb.add(c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice);
+        HIPCHK(c, xb.flush());
         return CD_OK;
     };
-    HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
-    if (int st = upload_have()) return st;
+    if (int st = upload_have(&c->h_model[0])) return st;   // (the chosen models ride along: one launch)
     if (p->plane_optimize) {
         ZERO_FILL(c, c->d_sums, sizeof(unsigned long long) * 10 * F);
         LAUNCH(c, launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums));
@@ -691,9 +719,13 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             else if (cl.n < 3) { st.done = 1; st.status = CD_ERR_FEW_CORRESPONDENCES; }
         }
     }
-    HIPCHK(c, xfer(c, c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice));
-    HIPCHK(c, xfer(c, c->d_work, c->h_work, sizeof(IcpWork) * std::max(nwork, 1), hipMemcpyHostToDevice));
-    HIPCHK(c, xfer(c, c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice));
+    {
+        XferBatch xb(c);   // (one launch)
+        xb.add(c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice);
+        if (nwork > 0) xb.add(c->d_work, c->h_work, sizeof(IcpWork) * nwork, hipMemcpyHostToDevice);
+        xb.add(c->d_st, c->h_st, sizeof(IcpState) * 2 * ncl, hipMemcpyHostToDevice);
+        HIPCHK(c, xb.flush());
+    }
     // (zeroed up front by the fused call for its FIRST ICP stage only: a batch that runs one stage per template fills them again)
     const bool pre_zeroed = c->batch_zeroed;
     c->batch_zeroed = false;
@@ -757,10 +789,12 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, ip));
         c->timing.icp_kernel_launches = 1;
         c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
-        HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
         if (n_lat == n_live) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            HIPCHK(c, xfer(c, c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost));
+            XferBatch xb(c);   // (one launch)
+            xb.add(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost);
+            xb.add(c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost);
+            HIPCHK(c, xb.flush());
             HIPCHK(c, hipStreamSynchronize(c->stream));
             float ms1 = 0.f;
             hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -775,6 +809,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             return CD_OK;
         }
         // mixed batch: the other clusters take the drivers below, which find these finished in d_st / h_st (the stream orders them)
+        HIPCHK(c, xfer(c, c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     // Batch mode: with at least ~n_cu/5 clusters every CU can own whole clusters, so each cluster runs its

@@ -399,13 +399,15 @@ void launch_pack_records(hipStream_t s, const float4* pts, int m, int words, int
 // behind other contexts' ICP launches, and every other context's copy on the same engine waits behind it (measured:
 // hipMemcpyAsync calls of ALL contexts blocking 5-8 ms at once, tools/hip_api_long_calls.sh).  A kernel is ordered by its own
 // stream only.  Rows of `width` bytes (a multiple of 4), `rows` of them, pitches in bytes; rows = 1 for a plain copy.
-__global__ void __launch_bounds__(BLOCK) k_copy_rows(uint32_t* __restrict__ dst, size_t dpitch_w, const uint32_t* __restrict__ src, size_t spitch_w,
-                                                     int width_w, int rows) {
-    for (int r = blockIdx.y; r < rows; r += gridDim.y)
-        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < width_w; i += gridDim.x * BLOCK) dst[(size_t)r * dpitch_w + i] = src[(size_t)r * spitch_w + i];
+__global__ void __launch_bounds__(BLOCK) k_copy_rows(CopyList L) {
+    CD_FRONT_PRIO();
+    const CopySeg sg = L.seg[blockIdx.y];
+    for (int r = blockIdx.z; r < sg.rows; r += gridDim.z)
+        for (int i = blockIdx.x * BLOCK + threadIdx.x; i < sg.width_w; i += gridDim.x * BLOCK) sg.dst[(size_t)r * sg.dpitch_w + i] = sg.src[(size_t)r * sg.spitch_w + i];
 }
 // every zero-initialised scratch array of a fused batch call in ONE launch (blockIdx.y = region) instead of a dozen fill kernels
 __global__ void __launch_bounds__(BLOCK) k_zero_regions(ZeroRegions r) {
+    CD_FRONT_PRIO();
     uint32_t* p = r.ptr[blockIdx.y];
     const size_t n = r.words[blockIdx.y];
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) p[i] = 0u;
@@ -413,11 +415,22 @@ __global__ void __launch_bounds__(BLOCK) k_zero_regions(ZeroRegions r) {
 void launch_zero_regions(hipStream_t s, const ZeroRegions& r) {
     if (r.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(128, r.n), dim3(BLOCK), 0, s, r);
 }
+// several transfers in ONE launch (blockIdx.y = transfer): consecutive copies of a stage cost one stream operation
+void launch_copy_list(hipStream_t s, const CopyList& L) {
+    if (L.n <= 0) return;
+    int gx = 1, gz = 1;
+    for (int k = 0; k < L.n; ++k) {
+        gx = std::max(gx, std::min(64, (L.seg[k].width_w + BLOCK - 1) / BLOCK));
+        gz = std::max(gz, std::min(L.seg[k].rows, 256));
+    }
+    hipLaunchKernelGGL(k_copy_rows, dim3(gx, L.n, gz), dim3(BLOCK), 0, s, L);
+}
 void launch_copy_rows(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows) {
     if (width == 0 || rows <= 0) return;
-    const int width_w = (int)(width / 4);
-    const int gx = std::min(64, (width_w + BLOCK - 1) / BLOCK), gy = std::min(rows, 1024);
-    hipLaunchKernelGGL(k_copy_rows, dim3(gx, gy), dim3(BLOCK), 0, s, (uint32_t*)dst, dpitch / 4, (const uint32_t*)src, spitch / 4, width_w, rows);
+    CopyList L;
+    L.n = 1;
+    L.seg[0] = CopySeg{(uint32_t*)dst, (const uint32_t*)src, dpitch / 4, spitch / 4, (int)(width / 4), rows};
+    launch_copy_list(s, L);
 }
 void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag) {
     if (n > 0) hipLaunchKernelGGL(k_passthrough_mark, dim3((n + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, s, (const char*)in, stride, n, field_off, lo, hi, negative, flag);

@@ -24,6 +24,9 @@ void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint3
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
 struct ZeroRegions { int n; uint32_t* ptr[16]; size_t words[16]; };
 void launch_zero_regions(hipStream_t s, const ZeroRegions& r);
+struct CopySeg { uint32_t* dst; const uint32_t* src; size_t dpitch_w, spitch_w; int width_w, rows; };   // pitches and width in 4-byte words
+struct CopyList { int n; CopySeg seg[8]; };
+void launch_copy_list(hipStream_t s, const CopyList& L);
 void launch_copy_rows(hipStream_t s, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, int rows);
 void launch_passthrough_mark(hipStream_t s, const void* in, size_t stride, int n, int field_off, double lo, double hi, int negative, int* flag);
 void launch_select_unmarked(hipStream_t s, const int* flag, int n, int* state, FrameState* fs, int* out, int* ticket);

@@ -19,6 +19,12 @@ from conftest import GOLDEN, ROOT
 from perception_amd import capi, synth, templates
 
 PCL_GOLDEN = os.path.join(GOLDEN, "pcl_frames_golden.json")
+# the tool's flavours (tools/pcl_golden.cpp): file it writes, and the cd_params that restate the same reference code
+FLAVOURS = {
+    "chain": ("pcl_frames_golden.json", {}),
+    "cuboid": ("pcl_frames_golden_cuboid.json", {"crop2_enable": 0, "cluster_enable": 0}),
+    "object": ("pcl_frames_golden_object.json", {"leaf_size": 0.001, "plane_distance_threshold": 0.01}),
+}
 
 
 def test_pcl_golden_tool_parses_against_the_stand_ins():
@@ -36,14 +42,42 @@ def test_frame_writer_for_the_pcl_tool(tmp_path):
     assert open(tmp_path / "template.pcd", "rb").read() == templates.template_pcd_bytes(**templates.DEFAULT_TEMPLATE)
 
 
-@pytest.mark.skipif(not os.path.exists(PCL_GOLDEN),
-                    reason="parity unpinned: tests/golden/pcl_frames_golden.json does not exist - it takes a machine with PCL "
-                           "(tools/pcl_golden.cpp); nothing in this repository may claim parity with real PCL until it does")
-def test_oracle_against_real_pcl(O):
-    gold = json.load(open(PCL_GOLDEN))
+def test_flavours_of_the_tool_are_the_parameter_sets_the_oracle_runs(O):
+    """the tool's three flavours exist in its source, and the oracle runs each parameter set on frame 0 (so a golden file of any
+    flavour can be compared the day it appears): the cuboid flavour has exactly one ICP source = the whole extracted cloud"""
+    src = open(os.path.join(ROOT, "tools", "pcl_golden.cpp")).read()
+    tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
+    f = synth.frame(0)
+    seen = {}
+    for name, (_, over) in FLAVOURS.items():
+        assert '{"%s", ' % name in src
+        if name == "object":
+            continue        # (leaf 0.001: 110 k voxels per frame - the GPU suite and bench.py's object_launch leg run it against the oracle)
+        prm = capi.default_params()
+        prm.rgb_offset = 12
+        for k, v in over.items():
+            setattr(prm, k, v)
+        seen[name] = O.process_frame(f, prm, tpl, nn_mode=1, want_clouds=True)
+    a, b = seen["chain"]["result"], seen["cuboid"]["result"]
+    assert (a.n_cropped, a.n_voxels, a.n_plane) == (b.n_cropped, b.n_voxels, b.n_plane)
+    assert b.n_clusters == 1 and b.clusters[0].size == b.n_objects >= a.n_objects
+    assert not seen["cuboid"]["labels"].any()
+
+
+@pytest.mark.parametrize("flavour", sorted(FLAVOURS))
+def test_oracle_against_real_pcl(O, flavour):
+    fname, over = FLAVOURS[flavour]
+    path = os.path.join(GOLDEN, fname)
+    if not os.path.exists(path):
+        pytest.skip("parity unpinned: tests/golden/%s does not exist - it takes a machine with PCL (tools/pcl_golden.cpp, flavour "
+                    "'%s'); nothing in this repository may claim parity with real PCL until it does" % (fname, flavour))
+    gold = json.load(open(path))
+    assert gold.get("flavour", "chain") == flavour
     tpl = templates.template_xyz32(**templates.DEFAULT_TEMPLATE)
     prm = capi.default_params()
     prm.rgb_offset = 12
+    for k, v in over.items():
+        setattr(prm, k, v)
     for e in gold["frames"]:
         f = synth.frame(e["index"])
         assert hashlib.sha256(f.tobytes()).hexdigest() == e["frame_sha256"], "the PCL run used other frames"

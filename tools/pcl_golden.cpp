@@ -11,7 +11,17 @@
 //   python tools/write_synth_frames.py /tmp/frames 4            # frame_0.bin .. frame_3.bin (x y z rgb float32) + template.pcd
 //   g++ -O2 -std=c++14 tools/pcl_golden.cpp -o pcl_golden $(pkg-config --cflags --libs pcl_common pcl_io pcl_filters
 //        pcl_segmentation pcl_search pcl_kdtree pcl_registration pcl_sample_consensus)
-//   ./pcl_golden /tmp/frames 4 tests/golden/pcl_frames_golden.json
+//   ./pcl_golden /tmp/frames 4 tests/golden/pcl_frames_golden.json              # flavour "chain" (default)
+//   ./pcl_golden /tmp/frames 4 tests/golden/pcl_frames_golden_cuboid.json cuboid
+//   ./pcl_golden /tmp/frames 2 tests/golden/pcl_frames_golden_object.json object
+//
+// Flavours (round 5; the parameter sets the tests and bench.py run, each as the reference's own code runs it):
+//   chain   object_pose_detection.cpp:270-413 (second z crop, clusters, one ICP per cluster) with cuboid_detection's launch
+//           values (leaf 0.005, threshold 0.015): cd_params' defaults, BASELINE configs 1-4
+//   cuboid  the cuboid_detection pair of nodes: ground_plane_segmentation.cpp:53-101 (no second crop) and
+//           iterative_closest_point.cpp:170-182 - the WHOLE extracted cloud is the one ICP source (no clustering:
+//           cd_params.crop2_enable = 0, cluster_enable = 0), accepted iff hasConverged() && getFitnessScore() < 0.0004
+//   object  the chain with object_detection.launch:30-38's values: leaf 0.001, threshold 0.01 (bench.py's object_launch leg)
 //
 // In this repository it is only PARSED (g++ -fsyntax-only against the minimal stand-in headers of tests/pcl_stubs, like the
 // ROS node shims against tests/ros_stubs): that keeps it compiling as the code around it changes; it proves nothing about
@@ -107,8 +117,20 @@ struct Icp : pcl::IterativeClosestPoint<pcl::PointXYZ, pcl::PointXYZ> {
     int iterations() const { return nr_iterations_; }
 };
 
-// the launch values (ground_plane_segmentation.launch:14-18, iterative_closest_point.launch:42) and opd.cpp's constants
-const double voxel_size = 0.005, distance_threshold = 0.015, icp_fitness_score = 0.0004;
+// the launch values (ground_plane_segmentation.launch:14-18, iterative_closest_point.launch:42; object_detection.launch:30-38)
+// and opd.cpp's constants
+struct Flavour {
+    const char* name;
+    double voxel_size, distance_threshold;
+    bool second_crop, clusters;
+    const char* params;
+};
+const Flavour flavours[] = {
+    {"chain", 0.005, 0.015, true, true, "opd.cpp:270-413 with the cuboid launch values: leaf 0.005, threshold 0.015, second crop z [0, 0.75], clusters 0.02/200/25000, ICP 5000/1e-9/0.0004"},
+    {"cuboid", 0.005, 0.015, false, false, "gps.cpp:53-101 + icp.cpp:170-182: leaf 0.005, threshold 0.015, no second crop, the whole extracted cloud as one ICP source, ICP 5000/1e-9/0.0004"},
+    {"object", 0.001, 0.01, true, true, "opd.cpp:270-413 with object_detection.launch's values: leaf 0.001, threshold 0.01, second crop z [0, 0.75], clusters 0.02/200/25000, ICP 5000/1e-9/0.0004"},
+};
+const double icp_fitness_score = 0.0004;
 const bool invert = true;
 
 std::string hexf(double v) { char b[64]; std::snprintf(b, sizeof(b), "%a", v); return b; }
@@ -116,15 +138,23 @@ std::string hexf(double v) { char b[64]; std::snprintf(b, sizeof(b), "%a", v); r
 }  // namespace
 
 int main(int argc, char** argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: pcl_golden <dir with frame_<i>.bin and template.pcd> <n_frames> <out.json>\n"); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: pcl_golden <dir with frame_<i>.bin and template.pcd> <n_frames> <out.json> [chain|cuboid|object]\n"); return 2; }
+    const Flavour* fl = &flavours[0];
+    if (argc > 4) {
+        fl = nullptr;
+        for (const Flavour& c : flavours) if (std::strcmp(c.name, argv[4]) == 0) fl = &c;
+        if (!fl) { std::fprintf(stderr, "unknown flavour %s\n", argv[4]); return 2; }
+    }
+    const double voxel_size = fl->voxel_size, distance_threshold = fl->distance_threshold;
     const std::string dir = argv[1];
     const int nf = std::atoi(argv[2]);
     pcl::PointCloud<pcl::PointXYZ>::Ptr template_cuboid(new pcl::PointCloud<pcl::PointXYZ>);
     if (pcl::io::loadPCDFile<pcl::PointXYZ>(dir + "/template.pcd", *template_cuboid) == -1) { std::fprintf(stderr, "no template\n"); return 2; }   // opd.cpp:398
     FILE* out = std::fopen(argv[3], "w");
     if (!out) return 2;
-    std::fprintf(out, "{\n \"params\": \"cuboid launch values: leaf 0.005, threshold 0.015, clusters 0.02/200/25000, ICP 5000/1e-9/0.0004\",\n"
-                      " \"made_by\": \"tools/pcl_golden.cpp with PCL %d.%d.%d\",\n \"frames\": [\n", PCL_MAJOR_VERSION, PCL_MINOR_VERSION, PCL_REVISION_VERSION);
+    std::fprintf(out, "{\n \"flavour\": \"%s\",\n \"params\": \"%s\",\n"
+                      " \"made_by\": \"tools/pcl_golden.cpp with PCL %d.%d.%d\",\n \"frames\": [\n", fl->name, fl->params, PCL_MAJOR_VERSION, PCL_MINOR_VERSION,
+                 PCL_REVISION_VERSION);
     for (int fi = 0; fi < nf; ++fi) {
         // the frame as the D435 driver's PointCloud2 carries it: x y z rgb, float32
         pcl::PointCloud<pcl::PointXYZRGB>::Ptr frame(new pcl::PointCloud<pcl::PointXYZRGB>);
@@ -169,19 +199,27 @@ int main(int argc, char** argv) {
         pcl::PCLPointCloud2* np_ = new pcl::PCLPointCloud2; pcl::PCLPointCloud2ConstPtr npPtr(np_);
         pcl::ExtractIndices<pcl::PCLPointCloud2> extract;
         extract.setInputCloud(vxPtr); extract.setIndices(inliers); extract.setNegative(invert); extract.filter(*np_);
-        // opd.cpp:331-336  second PassThrough z [0, 0.75]
-        pcl::PCLPointCloud2* cl = new pcl::PCLPointCloud2;
-        pass.setInputCloud(npPtr); pass.setFilterFieldName("z"); pass.setFilterLimits(0.0, 0.75); pass.filter(*cl);
         pcl::PointCloud<pcl::PointXYZ>::Ptr objects(new pcl::PointCloud<pcl::PointXYZ>);
-        pcl::fromPCLPointCloud2(*cl, *objects);
-        delete cl;
-        // opd.cpp:345-362  KdTree + EuclideanClusterExtraction 0.02 / 200 / 25000
-        pcl::search::KdTree<pcl::PointXYZ>::Ptr tree(new pcl::search::KdTree<pcl::PointXYZ>);
-        tree->setInputCloud(objects);
+        if (fl->second_crop) {   // opd.cpp:331-336  second PassThrough z [0, 0.75]
+            pcl::PCLPointCloud2* cl = new pcl::PCLPointCloud2;
+            pass.setInputCloud(npPtr); pass.setFilterFieldName("z"); pass.setFilterLimits(0.0, 0.75); pass.filter(*cl);
+            pcl::fromPCLPointCloud2(*cl, *objects);
+            delete cl;
+        } else {                 // gps.cpp:104-112 publishes the extracted cloud as it is; icp.cpp:156 reads it back
+            pcl::fromPCLPointCloud2(*np_, *objects);
+        }
         std::vector<pcl::PointIndices> clusters;
-        pcl::EuclideanClusterExtraction<pcl::PointXYZ> ec;
-        ec.setClusterTolerance(0.02); ec.setMinClusterSize(200); ec.setMaxClusterSize(25000); ec.setSearchMethod(tree); ec.setInputCloud(objects);
-        ec.extract(clusters);
+        if (fl->clusters) {      // opd.cpp:345-362  KdTree + EuclideanClusterExtraction 0.02 / 200 / 25000
+            pcl::search::KdTree<pcl::PointXYZ>::Ptr tree(new pcl::search::KdTree<pcl::PointXYZ>);
+            tree->setInputCloud(objects);
+            pcl::EuclideanClusterExtraction<pcl::PointXYZ> ec;
+            ec.setClusterTolerance(0.02); ec.setMinClusterSize(200); ec.setMaxClusterSize(25000); ec.setSearchMethod(tree); ec.setInputCloud(objects);
+            ec.extract(clusters);
+        } else if (!objects->points.empty()) {   // icp.cpp:171: the whole cloud is the source (label 0 for every point)
+            pcl::PointIndices all;
+            for (size_t i = 0; i < objects->points.size(); ++i) all.indices.push_back((int)i);
+            clusters.push_back(all);
+        }
         // canonical labels: rank by (size descending, first member index ascending); PCL's own order is by size
         // with ties unspecified
         std::vector<int> order(clusters.size());
@@ -190,7 +228,7 @@ int main(int argc, char** argv) {
             if (clusters[a].indices.size() != clusters[b].indices.size()) return clusters[a].indices.size() > clusters[b].indices.size();
             return *std::min_element(clusters[a].indices.begin(), clusters[a].indices.end()) < *std::min_element(clusters[b].indices.begin(), clusters[b].indices.end());
         });
-        std::vector<int32_t> labels(objects->size(), -1), inl(inliers->indices.begin(), inliers->indices.end());
+        std::vector<int32_t> labels(objects->size(), fl->clusters ? -1 : 0), inl(inliers->indices.begin(), inliers->indices.end());
         for (size_t r = 0; r < order.size(); ++r) for (int i : clusters[order[r]].indices) labels[(size_t)i] = (int32_t)r;
         std::vector<float> vox;
         for (const auto& p : voxel_ptr->points) { vox.push_back(p.x); vox.push_back(p.y); vox.push_back(p.z); }
