@@ -246,16 +246,22 @@ extern "C" int cd_debug_lat_stats(unsigned long long* out, int reset) {
 #define LAT_T(k)
 #endif
 
-// Rule C4's fixed-point term rint(v * 2^shift) WITHOUT taking it out of the double: u = fma(v, 2^shift, 1.5 * 2^52) is exact
-// in its product and rounds once (nearest even) in its sum, and for |v * 2^shift| < 2^50 the BITS of u, read as an integer, are
-// C + rint(v * 2^shift) with C = 0x4338000000000000 (exponent field of [2^52, 2^53), mantissa 2^51 + r).  So a lane adds the raw
-// bits to its 64-bit accumulator - cvt, fma, one 64-bit add: three instructions per term where fixq_fast + add took eight -
-// and since EVERY lane of EVERY pass adds exactly one term to each sum (a lane without a point adds the term of 0, which is C),
-// the solver takes (passes x 64) x C off each sum again (mod 2^64, like the sums themselves).
-constexpr unsigned long long LAT_FIX_C = 0x4338000000000000ull;
-__device__ __forceinline__ unsigned long long lat_fix_bits(float v, double scale) {
-    return (unsigned long long)__double_as_longlong(__fma_rn((double)v, scale, 6755399441055744.0));
-}
+// Rule C4's fixed-point term rint(v * 2^SHIFT) WITHOUT taking it out of the double: u = (double)v + 1.5 * 2^(52 - SHIFT) is ONE
+// rounded addition (v is exact as a double; nearest even at 2^-SHIFT, the spacing of doubles in [2^(52-SHIFT), 2^(53-SHIFT))),
+// and for |v * 2^SHIFT| < 2^50 the BITS of u, read as an integer, are C + rint(v * 2^SHIFT) with C = the bits of the constant.
+// So a lane adds the raw bits to its 64-bit accumulator - cvt, one v_add_f64 with the constant as a scalar operand, one 64-bit
+// add - and since every POINT adds exactly one term to each sum, the solver takes n x C off each sum again (mod 2^64, like the
+// sums themselves).  (Until the end of round 5 this was fma(v, 2^SHIFT, 1.5 * 2^52): the same integers, but the compiler
+// rebuilt the addend in a register pair before every fma - two moves per term.)
+template <int SHIFT>
+struct LatFix {
+    static constexpr unsigned long long C = ((unsigned long long)(1023 + 52 - SHIFT) << 52) | (1ull << 51);   // bits of 1.5 * 2^(52 - SHIFT)
+    static __device__ __forceinline__ unsigned long long bits(float v) {
+        return (unsigned long long)__double_as_longlong(__dadd_rn((double)v, __longlong_as_double((long long)C)));
+    }
+};
+static_assert(LatFix<32>::C == 0x4138000000000000ull && LatFix<36>::C == 0x40f8000000000000ull, "constants of lat_fix");
+static_assert(FIX_SHIFT == 32 && FIX_SHIFT_D2 == 36, "k_icp_lat's moment sums are written for these scales");
 
 struct LatSlot {
     int k, src_off, n, tslot;   // the cluster (index, first point, points, template slot)
@@ -274,7 +280,6 @@ __global__ void __launch_bounds__(CPW * WPC * WAVE, CD_LAT_WAVES_PER_EU)
 k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
           unsigned long long* __restrict__ accf, const IcpLattice* __restrict__ lats, float4* __restrict__ src,
           const float4* __restrict__ src0, int* __restrict__ queue, unsigned long long* __restrict__ busy, IcpParams prm) {
-    constexpr int THREADS = CPW * WPC * WAVE;
     __shared__ float4 s_tab[CPW][LAT_MAX_TAB];
     __shared__ int4 s_face[CPW][2 * LAT_MAX_FACES];
     __shared__ unsigned long long s_acc[CPW][16];
@@ -368,32 +373,32 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                         if (act) pts[myq] = make_float4(px, py, pz, p.w);
                     }
                     const LatHit h = nf3 ? lat_nearest<true, 3>(tab, face, F, px, py, pz) : lat_nearest<true, LAT_MAX_FACES>(tab, face, F, px, py, pz);
-                    // the 16 moment terms of rule C4, accumulated as the raw bits of fma(v, 2^shift, 1.5 * 2^52) (lat_fix_bits above: the
-                    // solver takes the constants off again).  Valid while every term stays below 2^50 / 2^shift; a wave with a lane
-                    // outside that range (coordinates beyond 256 m, neighbours more than 128 m away) takes the general conversion -
-                    // the same integers either way.  A lane without a point contributes the terms of zero.
-                    const float pv[3] = {act ? px : 0.f, act ? py : 0.f, act ? pz : 0.f}, qv[3] = {act ? h.nx : 0.f, act ? h.ny : 0.f, act ? h.nz : 0.f};
-                    const float dv = act ? h.d : 0.f;
-                    const float big_c = fmaxf(fmaxf(fmaxf(fabsf(pv[0]), fabsf(pv[1])), fabsf(pv[2])), fmaxf(fmaxf(fabsf(qv[0]), fabsf(qv[1])), fabsf(qv[2])));
-                    const bool fast = ballot64(!(big_c < 256.f && dv < 16384.f)) == 0ull;
-                    if (fast) {
+                    // the 16 moment terms of rule C4, accumulated as raw bits (LatFix above: the solver takes the constants off
+                    // again).  Valid while every term stays below 2^50 / 2^shift; a point outside that range (coordinates beyond
+                    // 256 m, a neighbour more than 128 m away) takes the general conversion - the same integers either way.  Lanes
+                    // without a point add nothing.
+                    if (act) {
+                        const float pv[3] = {px, py, pz}, qv[3] = {h.nx, h.ny, h.nz};
+                        const float big_c = fmaxf(fmaxf(fmaxf(fabsf(px), fabsf(py)), fabsf(pz)), fmaxf(fmaxf(fabsf(h.nx), fabsf(h.ny)), fabsf(h.nz)));
+                        if (big_c < 256.f && h.d < 16384.f) {
 #pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            S[a] += lat_fix_bits(pv[a], 4294967296.0);
-                            S[3 + a] += lat_fix_bits(qv[a], 4294967296.0);
+                            for (int a = 0; a < 3; ++a) {
+                                S[a] += LatFix<FIX_SHIFT>::bits(pv[a]);
+                                S[3 + a] += LatFix<FIX_SHIFT>::bits(qv[a]);
 #pragma unroll
-                            for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += lat_fix_bits(__fmul_rn(qv[a], pv[b]), 4294967296.0);
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += LatFix<FIX_SHIFT>::bits(__fmul_rn(qv[a], pv[b]));
+                            }
+                            S[15] += LatFix<FIX_SHIFT_D2>::bits(h.d);
+                        } else {
+#pragma unroll
+                            for (int a = 0; a < 3; ++a) {
+                                S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT) + LatFix<FIX_SHIFT>::C;
+                                S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT) + LatFix<FIX_SHIFT>::C;
+#pragma unroll
+                                for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT) + LatFix<FIX_SHIFT>::C;
+                            }
+                            S[15] += (unsigned long long)fixq(h.d, FIX_SHIFT_D2) + LatFix<FIX_SHIFT_D2>::C;
                         }
-                        S[15] += lat_fix_bits(dv, 68719476736.0);
-                    } else {
-#pragma unroll
-                        for (int a = 0; a < 3; ++a) {
-                            S[a] += (unsigned long long)fixq(pv[a], FIX_SHIFT) + LAT_FIX_C;
-                            S[3 + a] += (unsigned long long)fixq(qv[a], FIX_SHIFT) + LAT_FIX_C;
-#pragma unroll
-                            for (int b = 0; b < 3; ++b) S[6 + 3 * a + b] += (unsigned long long)fixq(__fmul_rn(qv[a], pv[b]), FIX_SHIFT) + LAT_FIX_C;
-                        }
-                        S[15] += (unsigned long long)fixq(dv, FIX_SHIFT_D2) + LAT_FIX_C;
                     }
                 }
                 if (sub < npass) wave_fold_to_lds(S, 16, s_acc[slot]);
@@ -423,9 +428,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                     float qx, qy, qz;
                     xform(Tf, p0.x, p0.y, p0.z, qx, qy, qz);
                     const LatHit h = nf3 ? lat_nearest<false, 3>(tab, face, F, qx, qy, qz) : lat_nearest<false, LAT_MAX_FACES>(tab, face, F, qx, qy, qz);
-                    const float dv = act ? h.d : 0.f;
-                    const bool fast = ballot64(!(dv < 16384.f)) == 0ull;
-                    S[0] += fast ? lat_fix_bits(dv, 68719476736.0) : (unsigned long long)fixq(dv, FIX_SHIFT_D2) + LAT_FIX_C;
+                    if (act) S[0] += h.d < 16384.f ? LatFix<FIX_SHIFT_D2>::bits(h.d) : (unsigned long long)fixq(h.d, FIX_SHIFT_D2) + LatFix<FIX_SHIFT_D2>::C;
                 }
                 if (sub < npass) wave_fold_to_lds(S, 1, s_acc[slot]);
             }
@@ -439,10 +442,11 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
         if (threadIdx.x < CPW) {
             const int s = threadIdx.x;
             LatSlot& sl = s_slot[s];
-            // (every lane of every pass added LAT_FIX_C to each sum it touched: see lat_fix_bits)
-            const unsigned long long off = (unsigned long long)(((sl.n + 63) >> 6) * 64) * LAT_FIX_C;
+            // (every point added the constant of its scale to each sum it touched: see LatFix)
+            const unsigned long long off = (unsigned long long)sl.n * LatFix<FIX_SHIFT>::C, off_d = (unsigned long long)sl.n * LatFix<FIX_SHIFT_D2>::C;
             if (sl.phase == LAT_ITER && sl.ready) {
-                for (int i = 0; i < 16; ++i) s_acc[s][i] -= off;
+                for (int i = 0; i < 15; ++i) s_acc[s][i] -= off;
+                s_acc[s][15] -= off_d;
                 if (lat_solve(&s_so[s], s_acc[s], sl.n, prm)) sl.phase = LAT_FIT;
                 for (int i = 0; i < 16; ++i) s_acc[s][i] = 0ull;
                 sl.ready = 0;
@@ -451,7 +455,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
                 s_so[s].converged = 1;
                 st[2 * (size_t)sl.k] = s_so[s];
                 st[2 * (size_t)sl.k + 1] = s_so[s];
-                accf[sl.k] = s_acc[s][0] - off;
+                accf[sl.k] = s_acc[s][0] - off_d;
                 refill(s);
                 if (sl.phase != LAT_EMPTY) s_flags[1] = 1;
             }
