@@ -80,6 +80,8 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    int crop_direct = 1;                                          // CUBOID_CROP_DIRECT=0: the crop always copies the kept points (rounds 1-5)
+    int centroid_lanes = 1;                                       // CUBOID_CENTROID_LANES=0: the quad-per-voxel centroid kernel (rounds 3-5) instead of a lane per voxel
     bool voxel_runs = true;                                       // CUBOID_VOXEL_RUNS=0: S1 sorts the cropped points instead of their runs of equal voxel index
     int icp_slots = 0;                                            // CUBOID_ICP_SLOTS: clusters in flight per workgroup, 1 .. CD_PIPE_SLOTS (0: by regime)
     int icp_big_weight = 0;                                       // workgroup share of a template in global memory, per point (CUBOID_ICP_BIG_WEIGHT; 0 = by the launch's regime, measured on config 5)
@@ -386,6 +388,9 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // Round 4: the single-pass crop also writes the RUNS (one record per run of equal cell key inside a row of 64 input points)
     // and their digit histograms, and the sort runs on the packed cell keys themselves (k_crop_runs, k_voxel.hip)
     bool crop_runs = kp.enabled && c->crop_runs && c->voxel_runs && c->N <= (1 << 20);
+    // 16-byte records x y z rgb (the D435 driver's layout): k_crop_runs leaves the kept points where they are and the centroid
+    // kernel reads the input (0.5 GB less written and the same bytes read per 256-frame batch); any other layout is copied
+    const bool direct_pts = c->crop_direct && stride == 16 && (rgb_off == 12 || rgb_off < 0) && (reinterpret_cast<uintptr_t>(d_in) & 15u) == 0;
     int st = CD_OK;
     // (the ticket counters reset themselves at the end of every launch that uses them; zeroed here too so that a call that
     // failed half way can never leave the next one with a counter that is not zero)
@@ -399,7 +404,7 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
             ZERO_FILL(c, c->d_tile64, sizeof(unsigned long long) * (size_t)F * T);
             ZERO_FILL(c, c->d_ghist, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX);
             LAUNCH(c, launch_crop_runs(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tile64, c->d_cpt, c->d_key[0], c->d_val[0],
-                             c->d_ghist, c->d_ticket));
+                             c->d_ghist, c->d_ticket, direct_pts ? 1 : 0));
             LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, c->d_ghist));
         } else if (kp.enabled) {
             LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0], c->d_ticket));
@@ -457,7 +462,8 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // offset come from a chained scan (state in d_tileA)
     ZERO_FILL(c, c->d_tileC, sizeof(int) * (size_t)F * T);
     if (crop_runs || by_runs)
-        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, crop_runs ? Tc_runs : Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileC, c->d_vox, c->d_ticket));
+        LAUNCH(c, launch_voxel_centroid_runs(c->stream, c->d_key[cur], vin, crop_runs && direct_pts ? reinterpret_cast<const float4*>(d_in) : c->d_cpt, c->N, F, T, crop_runs ? Tc_runs : Tc,
+                                             rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileC, c->d_vox, c->d_ticket, c->centroid_lanes, crop_runs && direct_pts ? N : c->N));
     else
         LAUNCH(c, launch_voxel_centroid(c->stream, c->d_key[cur], vin, c->d_cpt, c->N, F, T, Tc, rgb_off >= 0 ? 1 : 0, c->d_fs, c->d_tileC, c->d_vox, c->d_ticket));
     if (rounds_out) *rounds_out = 0;
@@ -1556,6 +1562,8 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_ZERO_ONCE")) c->zero_once = std::atoi(m);
     if (const char* m = std::getenv("CUBOID_LAT_SHAPE")) std::sscanf(m, "%d,%d,%d", &c->lat_shape[0], &c->lat_shape[1], &c->lat_shape[2]);
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_CENTROID_LANES")) c->centroid_lanes = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_CROP_DIRECT")) c->crop_direct = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

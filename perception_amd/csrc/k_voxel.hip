@@ -352,7 +352,9 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
                                                      int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
                                                      FrameState* __restrict__ fs, unsigned long long* __restrict__ state,
                                                      float4* __restrict__ cpt, uint32_t* __restrict__ rkeys, uint32_t* __restrict__ rvals,
-                                                     uint32_t* __restrict__ ghist, int* __restrict__ ticket) {
+                                                     uint32_t* __restrict__ ghist, int* __restrict__ ticket, int direct) {
+    // direct != 0 (16-byte input records x y z rgb): the kept points are NOT copied - a run's record carries its start in the INPUT
+    // (runs are pieces of a row of the input, so their points are consecutive there too) and the centroid kernel reads the input
     CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK], s_rcnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
@@ -443,7 +445,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
     for (int j = 0; j < ITEMS; ++j) {
         const bool kept = (bal[j] >> lane) & 1ull;
         const int r = pos + __popcll(bal[j] & lt);
-        if (kept && r < pitch) cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
+        if (!direct && kept && r < pitch) cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
         const bool is_head = (heads[j] >> lane) & 1ull;
         if (is_head) {
             // the run ends at the next head or at the first point of the row that is not kept, whichever comes first
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
             s_rk[ro - rexcl0] = key;
             if (ro < pitch) {
                 rkeys[obase + ro] = key;
-                rvals[obase + ro] = (uint32_t)r | ((uint32_t)(next - lane) << RUN_SHIFT_C);
+                rvals[obase + ro] = (uint32_t)(direct ? base + j * WAVE + lane : r) | ((uint32_t)(next - lane) << RUN_SHIFT_C);
             }
         }
         pos += __popcll(bal[j]);
@@ -617,7 +619,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                                                                const uint32_t* __restrict__ vals,
                                                                const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
                                                                FrameState* __restrict__ fs, int* __restrict__ state,
-                                                               float4* __restrict__ vox, int* __restrict__ ticket) {
+                                                               float4* __restrict__ vox, int* __restrict__ ticket, int pts_pitch) {
     CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK];
     __shared__ int s_head[TILE];
@@ -629,6 +631,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
     const size_t fbase = (size_t)f * N;
     const uint32_t* k = keys + fbase;
     const uint32_t* v = vals + fbase;
+    const float4* pts = cpt + (size_t)f * pts_pitch;   // (the cropped points, or - k_crop_runs' direct form - the input records themselves)
     const int base = tile * TILE + w * WAVE_SPAN;
     uint64_t bal[ITEMS];
     int wtot = 0;
@@ -708,7 +711,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                 if (len##I > 7) CD_ADD(Q, 3)                                                           \
                 for (int i = 8; i < len##I; i += 4) {   /* longer runs: the rest, four points per trip */ \
                     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);                                        \
-                    if (i + ql < len##I) t = cpt[fbase + start##I + i + ql];                           \
+                    if (i + ql < len##I) t = pts[start##I + i + ql];                           \
                     CD_ADD(t, 0)                                                                       \
                     if (len##I - i > 1) CD_ADD(t, 1)                                                   \
                     if (len##I - i > 2) CD_ADD(t, 2)                                                   \
@@ -728,14 +731,14 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
             if (have2) { kk2 = k[eb + 4 + ql]; rec2 = v[eb + 4 + ql]; }
             cnt += (len0 + len1) + (len2 + len3);   // (the voxel's point count is the sum of its runs' lengths: not counted point by point)
             float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0, q0 = p0, q1 = p0, q2 = p0, q3 = p0;
-            if (ql < len0) p0 = cpt[fbase + start0 + ql];
-            if (ql < len1) p1 = cpt[fbase + start1 + ql];
-            if (ql < len2) p2 = cpt[fbase + start2 + ql];
-            if (ql < len3) p3 = cpt[fbase + start3 + ql];
-            if (4 + ql < len0) q0 = cpt[fbase + start0 + 4 + ql];
-            if (4 + ql < len1) q1 = cpt[fbase + start1 + 4 + ql];
-            if (4 + ql < len2) q2 = cpt[fbase + start2 + 4 + ql];
-            if (4 + ql < len3) q3 = cpt[fbase + start3 + 4 + ql];
+            if (ql < len0) p0 = pts[start0 + ql];
+            if (ql < len1) p1 = pts[start1 + ql];
+            if (ql < len2) p2 = pts[start2 + ql];
+            if (ql < len3) p3 = pts[start3 + ql];
+            if (4 + ql < len0) q0 = pts[start0 + 4 + ql];
+            if (4 + ql < len1) q1 = pts[start1 + 4 + ql];
+            if (4 + ql < len2) q2 = pts[start2 + 4 + ql];
+            if (4 + ql < len3) q3 = pts[start3 + 4 + ql];
             // the additions replay the input order: run by run, point by point
             CD_RUN(0, p0, q0) CD_RUN(1, p1, q1) CD_RUN(2, p2, q2) CD_RUN(3, p3, q3)
             if (len3 == 0) break;    // the voxel's runs ended inside this group of four
@@ -750,7 +753,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
                 const uint32_t r = v[e];
                 const int st = (int)(r & ((1u << 20) - 1u)), ln = (int)(r >> 20);
                 for (int i = 0; i < ln; ++i) {
-                    const uint32_t u = __float_as_uint(cpt[fbase + st + i].w);
+                    const uint32_t u = __float_as_uint(pts[st + i].w);
                     cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff);
                 }
             }
@@ -765,6 +768,149 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_runs(const uint32_t* _
             vox[fbase + out0 + h] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
         }
         h = hn; e0 = ne0; kk = nkk; rec = nrec; have = nhave;
+    }
+}
+
+// The same, ONE LANE PER VOXEL (end of round 5).  The quad form above spends four lanes on one sequential sum (every lane of a
+// quad executes every addition of its voxel) and sixteen voxels share a wave's instruction stream: 465 vector instructions per
+// sixteen voxels, a fifth of the pipeline's vector instructions - and with several batches in flight vector issue is what the
+// batches compete for.  Here a lane walks its own voxel: a window of four run records (fetched together;
+// the next window while this one is summed), and per trip eight points of the window's flat point sequence - run by run, point
+// by point: the input order of rule C2 - with all eight loads in flight together; slots beyond the voxel read nothing and add
+// +0, which leaves a sum that started at +0 unchanged bit for bit.  6.8 points in 2.9 runs per voxel on the bench frames: most
+// voxels are one trip.  A wave's trips = the longest voxel's among its 64; every lane divides and stores for its own voxel.
+__global__ void __launch_bounds__(BLOCK) k_voxel_centroid_lanes(const uint32_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ vals,
+                                                                const float4* __restrict__ cpt, int N, int T, int Tact, int rgb_on,
+                                                                FrameState* __restrict__ fs, int* __restrict__ state,
+                                                                float4* __restrict__ vox, int* __restrict__ ticket, int pts_pitch) {
+    CD_FRONT_PRIO();
+    __shared__ int s_cnt[WAVES_PER_BLOCK];
+    __shared__ int s_head[TILE];
+    __shared__ int s_out0, s_ticket;
+    const int F = gridDim.x / Tact;
+    const int f = blockIdx.x % F, tile = take_ticket(ticket + f * TICKET_PITCH, Tact, &s_ticket), w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int n = fs[f].n_runs;
+    if (tile * TILE >= n) return;
+    const size_t fbase = (size_t)f * N;
+    const uint32_t* k = keys + fbase;
+    const uint32_t* v = vals + fbase;
+    const float4* pts = cpt + (size_t)f * pts_pitch;   // (the cropped points, or - k_crop_runs' direct form - the input records themselves)
+    const int base = tile * TILE + w * WAVE_SPAN;
+    uint64_t bal[ITEMS];
+    int wtot = 0;
+    head_ballots<ITEMS>(k, base, n, bal);
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) wtot += __popcll(bal[j]);
+    if (lane == 0) s_cnt[w] = wtot;
+    __syncthreads();
+    int pos = 0, nheads = 0;
+    for (int q = 0; q < WAVES_PER_BLOCK; ++q) { if (q < w) pos += s_cnt[q]; nheads += s_cnt[q]; }
+    if (threadIdx.x == 0) {
+        const int excl = chained_scan(state + (size_t)f * T, 1, tile, nheads, &fs[f].scan_stalled);
+        s_out0 = excl;
+        if ((tile + 1) * TILE >= n) fs[f].n_v = excl + nheads;
+    }
+    const uint64_t lt = lanemask_lt();
+#pragma unroll
+    for (int j = 0; j < ITEMS; ++j) {
+        if ((bal[j] >> lane) & 1ull) s_head[pos + __popcll(bal[j] & lt)] = base + j * WAVE + lane;
+        pos += __popcll(bal[j]);
+    }
+    __syncthreads();
+    const int out0 = s_out0;
+    constexpr uint32_t START = (1u << 20) - 1u;
+    // a window of four run records (the voxel's runs are a prefix of it); the first window of a lane's NEXT voxel is fetched
+    // while the current voxel is summed (a wave takes the tile's voxels 64 at a time, 256 apart)
+    struct Win { int e; uint32_t key, k0, k1, k2, k3, v0, v1, v2, v3; };
+    auto first_window = [&](int hh) {
+        Win W;
+        W.e = 0; W.key = 0; W.k0 = W.k1 = W.k2 = W.k3 = 0; W.v0 = W.v1 = W.v2 = W.v3 = 0;
+        if (hh < nheads) {
+            const int e = s_head[hh];
+            W.e = e;
+            W.key = k[e];
+            W.k0 = W.key; W.v0 = v[e];
+            W.k1 = W.k2 = W.k3 = ~W.key;
+            if (e + 1 < n) { W.k1 = k[e + 1]; W.v1 = v[e + 1]; }
+            if (e + 2 < n) { W.k2 = k[e + 2]; W.v2 = v[e + 2]; }
+            if (e + 3 < n) { W.k3 = k[e + 3]; W.v3 = v[e + 3]; }
+        }
+        return W;
+    };
+    Win nextw = first_window(w * WAVE + lane);
+    for (int h0 = w * WAVE; h0 < nheads; h0 += BLOCK) {   // (uniform per wave: ballots inside)
+        const int h = h0 + lane;
+        bool alive = h < nheads;
+        const Win cw = nextw;
+        nextw = first_window(h + BLOCK);
+        int e = cw.e, i = 0, cnt = 0;
+        const uint32_t key = cw.key;
+        uint32_t wk0 = cw.k0, wk1 = cw.k1, wk2 = cw.k2, wk3 = cw.k3, wv0 = cw.v0, wv1 = cw.v1, wv2 = cw.v2, wv3 = cw.v3;
+        uint32_t nk0 = 0, nk1 = 0, nk2 = 0, nk3 = 0, nv0 = 0, nv1 = 0, nv2 = 0, nv3 = 0;
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+        uint32_t ir = 0, ig = 0, ib = 0;
+        while (ballot64(alive)) {
+            const bool m0 = alive && wk0 == key, m1 = m0 && wk1 == key, m2 = m1 && wk2 == key, m3 = m2 && wk3 == key;
+            const int l0 = m0 ? (int)(wv0 >> 20) : 0, l1 = m1 ? (int)(wv1 >> 20) : 0, l2 = m2 ? (int)(wv2 >> 20) : 0, l3 = m3 ? (int)(wv3 >> 20) : 0;
+            const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, tot = c3 + l3;
+            const int s0 = (int)(wv0 & START), s1 = (int)(wv1 & START) - c1, s2 = (int)(wv2 & START) - c2, s3 = (int)(wv3 & START) - c3;   // (start - first flat index of the run)
+            if (m3 && i == 0) {   // first trip of a full window: the voxel may go on
+                nk0 = nk1 = nk2 = nk3 = ~key;
+                if (e + 4 < n) { nk0 = k[e + 4]; nv0 = v[e + 4]; }
+                if (e + 5 < n) { nk1 = k[e + 5]; nv1 = v[e + 5]; }
+                if (e + 6 < n) { nk2 = k[e + 6]; nv2 = v[e + 6]; }
+                if (e + 7 < n) { nk3 = k[e + 7]; nv3 = v[e + 7]; }
+            }
+            // eight points of the window's flat sequence (run by run, point by point), all eight loads in flight together
+            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 P[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int idx = i + t;
+                const int off = idx >= c3 ? s3 : (idx >= c2 ? s2 : (idx >= c1 ? s1 : s0));
+                P[t] = z;
+                if (idx < tot) P[t] = pts[off + idx];
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                sx = __fadd_rn(sx, P[t].x); sy = __fadd_rn(sy, P[t].y); sz = __fadd_rn(sz, P[t].z);
+                if (rgb_on) {
+                    const uint32_t u = __float_as_uint(P[t].w);
+                    ir = __builtin_amdgcn_udot4(u, 0x00010000u, ir, false);
+                    ig = __builtin_amdgcn_udot4(u, 0x00000100u, ig, false);
+                    ib = __builtin_amdgcn_udot4(u, 0x00000001u, ib, false);
+                }
+            }
+            i += 8;
+            if (alive && i >= tot) {   // the window is summed
+                cnt += tot;
+                alive = m3 && nk0 == key;
+                e += 4; i = 0;
+                wk0 = nk0; wk1 = nk1; wk2 = nk2; wk3 = nk3; wv0 = nv0; wv1 = nv1; wv2 = nv2; wv3 = nv3;
+            }
+        }
+        if (h < nheads) {
+            float cr = (float)ir, cg = (float)ig, cb = (float)ib;
+            if (rgb_on && cnt > 65536) {   // partial sums beyond 2^24 round in PCL's float accumulation: replay it
+                cr = cg = cb = 0.f;
+                for (int ee = s_head[h]; ee < n && k[ee] == key; ++ee) {
+                    const uint32_t r = v[ee];
+                    const int s0 = (int)(r & START), ln = (int)(r >> 20);
+                    for (int i = 0; i < ln; ++i) {
+                        const uint32_t u = __float_as_uint(pts[s0 + i].w);
+                        cr += (float)((u >> 16) & 0xff); cg += (float)((u >> 8) & 0xff); cb += (float)(u & 0xff);
+                    }
+                }
+            }
+            const float c = (float)cnt;
+            uint32_t packed = 0;
+            if (rgb_on) {
+                const int R = (int)__fdiv_rn(cr, c), G = (int)__fdiv_rn(cg, c), B = (int)__fdiv_rn(cb, c);
+                packed = ((uint32_t)R << 16) | ((uint32_t)G << 8) | (uint32_t)B;
+            }
+            vox[fbase + out0 + h] = make_float4(__fdiv_rn(sx, c), __fdiv_rn(sy, c), __fdiv_rn(sz, c), __uint_as_float(packed));
+        }
     }
 }
 
@@ -795,18 +941,22 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
 }
 void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                       int T, float leaf, KeyPack kp, FrameState* fs, unsigned long long* state, float4* cpt, uint32_t* rkeys,
-                      uint32_t* rvals, uint32_t* ghist, int* ticket) {
+                      uint32_t* rvals, uint32_t* ghist, int* ticket, int direct) {
     const int Tin = (N + TILE - 1) / TILE;
     hipLaunchKernelGGL(k_crop_runs, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
-                       leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket);
+                       leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket, direct);
 }
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {
     hipLaunchKernelGGL(k_voxel_centroid, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket);
 }
 void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {
-    hipLaunchKernelGGL(k_voxel_centroid_runs, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket);
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket, int lanes, int pts_pitch) {
+    if (lanes) {
+        hipLaunchKernelGGL(k_voxel_centroid_lanes, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket, pts_pitch);
+        return;
+    }
+    hipLaunchKernelGGL(k_voxel_centroid_runs, dim3(Tact * F), dim3(BLOCK), 0, s, keys, vals, cpt, N, T, Tact, rgb_on, fs, state, vox, ticket, pts_pitch);
 }
 
 }  // namespace cd

@@ -13,13 +13,13 @@ void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int 
                        int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket);
 void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                       int T, float leaf, KeyPack kp, FrameState* fs, unsigned long long* state, float4* cpt, uint32_t* rkeys,
-                      uint32_t* rvals, uint32_t* ghist, int* ticket);
+                      uint32_t* rvals, uint32_t* ghist, int* ticket, int direct);
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys);
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
 void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
-                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket);
+                                int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket, int lanes, int pts_pitch);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
 struct ZeroRegions { int n; uint32_t* ptr[16]; size_t words[16]; };
