@@ -137,7 +137,7 @@ struct IcpLattice {
     int32_t ntab;                  // entries of tab in use
     int32_t n[3];                  // entries of the axis tables X, Y, Z (0: no face varies along that axis)
     int32_t toff[3];               // first entry of each table in tab
-    float o[3], inv[3];            // T[0] of each table and 1 / step (the tables are uniform to 1/16 of a step: index guess)
+    float noi[3], inv[3];          // -T[0] / step and 1 / step of each table (the tables are uniform to 1/16 of a step): entry guess = q * inv + noi
     int32_t w[LAT_MAX_FACES];      // the face's constant axis
     int32_t fast[LAT_MAX_FACES];   // the axis whose index varies fastest: index = base + i_slow * n[fast] + i_fast
     int32_t base[LAT_MAX_FACES];   // original index of the face's first point (faces are consecutive, ascending)

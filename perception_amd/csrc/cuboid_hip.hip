@@ -1661,7 +1661,7 @@ static void lattice_detect(const float* xyz, int m, IcpLattice* out) {
         out->toff[a] = ntab;
         if (n == 0) {   // no face varies along this axis: a one-entry table, so that the kernel treats every axis alike (never read by a face)
             if (ntab + 1 > LAT_MAX_TAB) { std::memset(out, 0, sizeof(*out)); return; }
-            out->n[a] = 1; out->o[a] = 0.f; out->inv[a] = 1.f;
+            out->n[a] = 1; out->noi[a] = 0.f; out->inv[a] = 1.f;
             out->tab[ntab++] = make_float4(-INFINITY, 0.f, INFINITY, 0.f);
             continue;
         }
@@ -1670,7 +1670,7 @@ static void lattice_detect(const float* xyz, int m, IcpLattice* out) {
         const double step = ((double)T[(size_t)n - 1] - (double)T[0]) / (double)(n - 1);
         for (int i = 0; i < n; ++i)   // uniform to 1/16 of a step: the index guess of lat_axis is then at most one entry off
             if (!(std::fabs((double)T[(size_t)i] - ((double)T[0] + i * step)) <= step / 16.0)) { std::memset(out, 0, sizeof(*out)); return; }
-        out->o[a] = T[0];
+        out->noi[a] = (float)(-(double)T[0] / step);
         out->inv[a] = (float)(1.0 / step);
         for (int i = 0; i < n; ++i)
             out->tab[ntab + i] = make_float4(i > 0 ? T[(size_t)i - 1] : -INFINITY, T[(size_t)i], i + 1 < n ? T[(size_t)i + 1] : INFINITY, 0.f);

@@ -42,7 +42,7 @@ struct LatFaces {
     unsigned m0[LAT_MAX_FACES], m1[LAT_MAX_FACES], m2[LAT_MAX_FACES];   // ~0 when the face's constant axis is x / y / z
     float c[LAT_MAX_FACES];
     int nx, ny, nz, tox, toy, toz;   // entries and first entry of the axis tables (separate scalars: an array indexed by a face's axis would be put into scratch memory)
-    float ox, oy, oz, ivx, ivy, ivz;
+    float ox, oy, oz, ivx, ivy, ivz;   // (ox = -X[0] / step, ivx = 1 / step: IcpLattice::noi, inv)
 };
 
 // call from every thread of the workgroup; ends with a barrier
@@ -52,7 +52,7 @@ __device__ __forceinline__ void lat_stage(const IcpLattice* __restrict__ L, LatF
 #pragma unroll
     for (int f = 0; f < LAT_MAX_FACES; ++f) { F.m0[f] = L->m0[f]; F.m1[f] = L->m1[f]; F.m2[f] = L->m2[f]; F.c[f] = L->c[f]; }
     F.nx = L->n[0]; F.ny = L->n[1]; F.nz = L->n[2]; F.tox = L->toff[0]; F.toy = L->toff[1]; F.toz = L->toff[2];
-    F.ox = L->o[0]; F.oy = L->o[1]; F.oz = L->o[2]; F.ivx = L->inv[0]; F.ivy = L->inv[1]; F.ivz = L->inv[2];
+    F.ox = L->noi[0]; F.oy = L->noi[1]; F.oz = L->noi[2]; F.ivx = L->inv[0]; F.ivy = L->inv[1]; F.ivz = L->inv[2];
     for (int i = threadIdx.x; i < L->ntab; i += THREADS) s_tab[i] = L->tab[i];
     if (threadIdx.x < LAT_MAX_FACES) {
         const int f = threadIdx.x, w = L->w[f], u = L->fast[f], v = 3 - w - u;
@@ -71,11 +71,19 @@ __device__ __forceinline__ float lat_pick(unsigned m, float a, float b) {
 }
 
 // one axis: the table entry nearest to q.  f = fl(fl(q - T[i])^2) at the minimum, t = T[i], gap = f(i - 1) - f(i) (+inf at
-// i = 0; 0 = not known: the exact test decides).  Every axis has a table (one that no face varies along has the single entry 0).
-__device__ __forceinline__ void lat_axis(const float4* s_tab, int toff, int n, float o, float inv, float q, float& f, int& i, float& t,
-                                         float& gap) {
-    int ig = __float2int_rn(__fmul_rn(__fsub_rn(q, o), inv));   // (saturating conversion; NaN -> 0)
-    ig = min(max(ig, 0), n - 1);
+// i = 0; 0 = not known: the exact test decides), i = ig + di with di in {-1, 0, +1} (left as two flags: only the rare tie walk
+// needs the index).  Every axis has a table (one that no face varies along has the single entry 0).
+// The window's centre ig only has to be within one entry of the nearest one - all three of the window are evaluated exactly -
+// so it is taken from ONE fused multiply-add and a conversion that rounds half up (v_cvt_rpi_i32_f32): q * inv - o * inv sits
+// within 1e-4 entries of (q - o) * inv at these magnitudes, against the 7/16 of an entry the uniformity check leaves to spare.
+__device__ __forceinline__ void lat_axis(const float4* s_tab, int toff, int n, float o_inv_neg, float inv, float q, float& f, int& ig_out, bool& lo_out,
+                                         bool& hi_out, float& t, float& gap) {
+    int ig;
+    {
+        const float pos = __builtin_fmaf(q, inv, o_inv_neg);   // (an approximate position: not one of the canonical operations)
+        asm("v_cvt_rpi_i32_f32 %0, %1" : "=v"(ig) : "v"(pos));   // floor(pos + 0.5), saturating; NaN -> 0
+    }
+    ig = min(max(ig, 0), n - 1);   // (one v_med3_i32)
     const float4 W = s_tab[toff + ig];
     const float d0 = __fsub_rn(q, W.x), d1 = __fsub_rn(q, W.y), d2 = __fsub_rn(q, W.z);
     const float f0 = __fmul_rn(d0, d0), f1 = __fmul_rn(d1, d1), f2 = __fmul_rn(d2, d2);
@@ -83,9 +91,10 @@ __device__ __forceinline__ void lat_axis(const float4* s_tab, int toff, int n, f
     // (f is unimodal along the table, so f1 > f0 and f1 > f2 cannot both hold: at most one of lo / hi)
     const bool lo = f0 < f1;
     const bool hi = f2 < f1;
-    f = f1; i = ig; t = W.y; gap = g_mid;
-    f = lo ? f0 : f; i = lo ? ig - 1 : i; t = lo ? W.x : t; gap = lo ? 0.f : gap;
-    f = hi ? f2 : f; i = hi ? ig + 1 : i; t = hi ? W.z : t; gap = hi ? g_hi : gap;
+    f = f1; t = W.y; gap = g_mid;
+    f = lo ? f0 : f; t = lo ? W.x : t; gap = lo ? 0.f : gap;
+    f = hi ? f2 : f; t = hi ? W.z : t; gap = hi ? g_hi : gap;
+    ig_out = ig; lo_out = lo; hi_out = hi;
 }
 
 // d2 of a face point from the three per-axis terms, canonical association (x + y) + z
@@ -103,10 +112,13 @@ struct LatHit {
 template <bool TIES, int NF>
 __device__ __forceinline__ LatHit lat_nearest(const float4* s_tab, const int4* s_face, const LatFaces& F, float qx, float qy, float qz) {
     float fx, fy, fz, tx, ty, tz, gx, gy, gz;
+    int cx, cy, cz;
+    bool lox, hix, loy, hiy, loz, hiz;
     LatHit h;
-    lat_axis(s_tab, F.tox, F.nx, F.ox, F.ivx, qx, fx, h.ix, tx, gx);
-    lat_axis(s_tab, F.toy, F.ny, F.oy, F.ivy, qy, fy, h.iy, ty, gy);
-    lat_axis(s_tab, F.toz, F.nz, F.oz, F.ivz, qz, fz, h.iz, tz, gz);
+    lat_axis(s_tab, F.tox, F.nx, F.ox, F.ivx, qx, fx, cx, lox, hix, tx, gx);
+    lat_axis(s_tab, F.toy, F.ny, F.oy, F.ivy, qy, fy, cy, loy, hiy, ty, gy);
+    lat_axis(s_tab, F.toz, F.nz, F.oz, F.ivz, qz, fz, cz, loz, hiz, tz, gz);
+    h.ix = h.iy = h.iz = 0;
     h.d = __uint_as_float(0x7f800000u); h.face = 0;
 #pragma unroll
     for (int f = 0; f < NF; ++f) {
@@ -129,6 +141,7 @@ __device__ __forceinline__ LatHit lat_nearest(const float4* s_tab, const int4* s
         const bool maybe = gsel <= __fmul_rn(h.d, 4.76837158203125e-07f);   // 2^-21
         if (ballot64(maybe)) {
             // rare (a lane enters when its gap is within the rounding of the sum: iteration 0, mid-cell queries): one face at a time
+            h.ix = cx + (hix ? 1 : 0) - (lox ? 1 : 0); h.iy = cy + (hiy ? 1 : 0) - (loy ? 1 : 0); h.iz = cz + (hiz ? 1 : 0) - (loz ? 1 : 0);
             for (int f = 0; f < F.nface; ++f) {
                 const bool mine = maybe && h.face == f;
                 if (!ballot64(mine)) continue;
@@ -348,7 +361,7 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
 #pragma unroll
                 for (int f = 0; f < LAT_MAX_FACES; ++f) { F.m0[f] = L->m0[f]; F.m1[f] = L->m1[f]; F.m2[f] = L->m2[f]; F.c[f] = L->c[f]; }
                 F.nx = L->n[0]; F.ny = L->n[1]; F.nz = L->n[2]; F.tox = L->toff[0]; F.toy = L->toff[1]; F.toz = L->toff[2];
-                F.ox = L->o[0]; F.oy = L->o[1]; F.oz = L->o[2]; F.ivx = L->inv[0]; F.ivy = L->inv[1]; F.ivz = L->inv[2];
+                F.ox = L->noi[0]; F.oy = L->noi[1]; F.oz = L->noi[2]; F.ivx = L->inv[0]; F.ivy = L->inv[1]; F.ivz = L->inv[2];
             }
             const bool nf3 = F.nface <= 3;
             if (phase == LAT_ITER) {
