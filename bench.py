@@ -779,7 +779,7 @@ def main():
                     "wait_any_frac": (sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_ANY") else None,
                     "wait_inst_any_frac": (sq["SQ_WAIT_INST_ANY"] / sq["SQ_WAVE_CYCLES"]) if sq.get("SQ_WAIT_INST_ANY") else None,
                     "lds_bank_conflict_frac_of_lds_active": (sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]) if sq.get("SQ_LDS_IDX_ACTIVE") and sq.get("SQ_LDS_BANK_CONFLICT") else None,
-                    "vector_instructions_per_query_iteration": (sq["SQ_INSTS_VALU"] * 64.0 / (icp_balg / max(icp_launches / args.steps, 1) / 12.0)) if icp_balg else None}
+                    "vector_wave_instructions_per_64_query_pass": (sq["SQ_INSTS_VALU"] * 64.0 / (icp_balg / max(icp_launches / args.steps, 1) / 12.0)) if icp_balg else None}
             if cal:
                 sat = cal["saturation"]["valu_per_ns_per_simd"]
                 out_["pipe_frac"] = sq["SQ_INSTS_VALU"] / (SIMDS * launch_ms * 1e6 * sat)

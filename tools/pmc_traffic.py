@@ -29,7 +29,7 @@ def load(d, counter):
 # 0.500 / 0.500 / 1.002 / 1.501 of the bytes read for stream16 / stream4 / quad64 aligned / quad64 at 16-byte alignment, where a
 # segment straddles two 64-byte sectors half of the time).  The centroid kernels gather their points that way: factor 1 for them
 # (rounds 1-3 doubled every kernel's FETCH_SIZE, which overstated these two by the size of their gather).
-FETCH_FACTOR = {"k_voxel_centroid_runs": 1.0, "k_voxel_centroid": 1.0}
+FETCH_FACTOR = {"k_voxel_centroid_runs": 1.0, "k_voxel_centroid": 1.0, "k_voxel_centroid_lanes": 1.0}   # (lanes: 16 scattered bytes per lane - tallied in full like the quads' 64)
 
 fetch, nf = load(sys.argv[1], "FETCH_SIZE")
 write, _ = load(sys.argv[2], "WRITE_SIZE")
