@@ -348,18 +348,20 @@ __global__ void __launch_bounds__(BLOCK) k_crop_fused(const char* __restrict__ i
 // per wave on more threads goes the other way (4 rows x 512 threads 427 us, 2 x 1024 966 us: half the tiles in flight each
 // time), 16 rows x 128 threads gains nothing (349), and the ticket costs 3 us.
 constexpr int RUN_SHIFT_C = 20;   // as k_sort.hip's RUN_SHIFT: start < 2^20, length <= 64
+template <bool DIRECT>
 __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in, size_t stride, int N, int pitch,
                                                      int rgb_off, CropLimits lim, int T, int Tin, float leaf, KeyPack kp,
                                                      FrameState* __restrict__ fs, unsigned long long* __restrict__ state,
                                                      float4* __restrict__ cpt, uint32_t* __restrict__ rkeys, uint32_t* __restrict__ rvals,
-                                                     uint32_t* __restrict__ ghist, int* __restrict__ ticket, int direct) {
-    // direct != 0 (16-byte input records x y z rgb): the kept points are NOT copied - a run's record carries its start in the INPUT
+                                                     uint32_t* __restrict__ ghist, int* __restrict__ ticket) {
+    // DIRECT (16-byte input records x y z rgb): the kept points are NOT copied - a run's record carries its start in the INPUT
     // (runs are pieces of a row of the input, so their points are consecutive there too) and the centroid kernel reads the input
     CD_FRONT_PRIO();
     __shared__ int s_cnt[WAVES_PER_BLOCK], s_rcnt[WAVES_PER_BLOCK];
     __shared__ float s_mn[WAVES_PER_BLOCK][3], s_mx[WAVES_PER_BLOCK][3];
     __shared__ uint32_t s_h[4][RADIX];
-    __shared__ uint32_t s_rk[TILE];   // the tile's run keys in order (for the histograms)
+    __shared__ unsigned short s_rk[TILE];   // the tile's run heads in order, as element numbers: their keys are in s_key (for the histograms;
+                                            // 16 bits each: 16.6 KB of LDS per workgroup, eight workgroups per CU instead of seven at 20.6 KB)
     __shared__ uint32_t s_key[TILE];  // every element's key between the two phases (eight registers less per lane: one more wave per SIMD)
     __shared__ int s_excl, s_rexcl, s_ticket;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -445,7 +447,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
     for (int j = 0; j < ITEMS; ++j) {
         const bool kept = (bal[j] >> lane) & 1ull;
         const int r = pos + __popcll(bal[j] & lt);
-        if (!direct && kept && r < pitch) cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
+        if (!DIRECT && kept && r < pitch) cpt[obase + r] = make_float4(px[j], py[j], pz[j], __uint_as_float(pc[j]));
         const bool is_head = (heads[j] >> lane) & 1ull;
         if (is_head) {
             // the run ends at the next head or at the first point of the row that is not kept, whichever comes first
@@ -453,10 +455,10 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
             const int next = stop ? __ffsll((long long)stop) - 1 : 64;
             const int ro = rpos + __popcll(heads[j] & lt);
             const uint32_t key = s_key[w * WAVE_SPAN + j * WAVE + lane];
-            s_rk[ro - rexcl0] = key;
+            s_rk[ro - rexcl0] = (unsigned short)(w * WAVE_SPAN + j * WAVE + lane);
             if (ro < pitch) {
                 rkeys[obase + ro] = key;
-                rvals[obase + ro] = (uint32_t)(direct ? base + j * WAVE + lane : r) | ((uint32_t)(next - lane) << RUN_SHIFT_C);
+                rvals[obase + ro] = (uint32_t)(DIRECT ? base + j * WAVE + lane : r) | ((uint32_t)(next - lane) << RUN_SHIFT_C);
             }
         }
         pos += __popcll(bal[j]);
@@ -474,7 +476,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
         for (int q0 = w * WAVE; q0 < nr; q0 += BLOCK) {
             const int q = q0 + lane;
             const bool on = q < nr;
-            const uint32_t kq = on ? s_rk[q] : 0u;
+            const uint32_t kq = on ? s_key[s_rk[q]] : 0u;
             if (on) atomicAdd(&s_h[0][kq & (RADIX - 1)], 1u);
 #pragma unroll
             for (int d = 1; d < 4; ++d) {
@@ -943,8 +945,12 @@ void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int p
                       int T, float leaf, KeyPack kp, FrameState* fs, unsigned long long* state, float4* cpt, uint32_t* rkeys,
                       uint32_t* rvals, uint32_t* ghist, int* ticket, int direct) {
     const int Tin = (N + TILE - 1) / TILE;
-    hipLaunchKernelGGL(k_crop_runs, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
-                       leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket, direct);
+    if (direct)
+        hipLaunchKernelGGL(k_crop_runs<true>, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
+                           leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket);
+    else
+        hipLaunchKernelGGL(k_crop_runs<false>, dim3(Tin * F), dim3(BLOCK), 0, s, (const char*)in, stride, N, pitch, rgb_off, lim, T, Tin,
+                           leaf, kp, fs, state, cpt, rkeys, rvals, ghist, ticket);
 }
 void launch_voxel_centroid(hipStream_t s, const uint32_t* keys, const uint32_t* vals, const float4* cpt, int N, int F,
                            int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket) {
