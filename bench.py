@@ -788,7 +788,7 @@ def main():
             return out_
         if args.config == 3 and lattice:
             v_in = _valu_block(PMC_SQ_INFLIGHT_SHAPE_FILES, avg_launch_ms, "4 clusters x 2 waves per workgroup (forced with CUBOID_LAT_SHAPE=4,2: the shape of the timed region), one launch alone - counters serialise kernels")
-            v_ex = _valu_block(PMC_SQ_FILES, exclusive["avg_launch_ms"] if exclusive else None, "1 cluster x 4 waves per workgroup: the shape a call with the GPU to itself picks")
+            v_ex = _valu_block(PMC_SQ_FILES, exclusive["avg_launch_ms"] if exclusive else None, "1 cluster per workgroup x 8 waves (522 clusters): the shape a call with the GPU to itself picks")
             if v_in or v_ex:
                 valu = {"in_flight_shape": v_in, "exclusive_shape": v_ex,
                         "note": "pipe_frac = vector wave-instructions of the launch / (1024 SIMDs x launch duration x the saturated vector rate of "

@@ -777,13 +777,13 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         std::stable_sort(c->h_order, c->h_order + no, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
         HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
         // Shape of the launch (k_icp_lat.hip): clusters per workgroup x waves per cluster.  A call that has the GPU to itself wants
-        // the launch short: one cluster per workgroup, four waves each when there are clusters enough to fill the chip that way,
-        // eight or sixteen for few or very large clusters (one frame; config 5's thousands of points).  With other batches in
+        // the launch short: one cluster per workgroup, four waves each when there are clusters enough to fill the chip twice that way,
+        // eight or sixteen for fewer or very large clusters (one frame; config 5's thousands of points).  With other batches in
         // flight the chip is full anyway: four clusters per workgroup, two waves each, pay the single-lane solve of a round once
         // for the four (measured on config 3, seven in flight, profiles/r05_lat_shapes.txt: 1x4 145-146 k, 4x2 149-151 k, 8x2 146 k,
         // 4x4 139 k, 4x1 131 k frames/s; alone 1x4 1.34 ms, 1x8 1.30, 4x2 2.2, 4x1 2.8).  CUBOID_LAT_SHAPE=cpw,wpc[,clusters per slot].
         const bool busy = g_batches_in_flight[c->device & (MAX_DEVICES - 1)].load() >= 3;
-        int cpw = 1, wpc = n_lat >= 384 ? 4 : (n_lat >= 96 ? 8 : 16), per_slot = 1;
+        int cpw = 1, wpc = n_lat >= 768 ? 4 : (n_lat >= 96 ? 8 : 16), per_slot = 1;   // (end of round 5, 522 clusters alone: 1x4 1.17 ms, 1x8 1.10, 1x16 1.53, 2x4 1.27)
         if (lat_max_n > 16384) wpc = 16;
         else if (lat_max_n > 4096) wpc = std::max(wpc, 8);
         if (busy && n_lat >= 256 && lat_max_n <= 8192) { cpw = 4; wpc = 2; }

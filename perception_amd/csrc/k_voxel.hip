@@ -822,33 +822,23 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_lanes(const uint32_t* 
     __syncthreads();
     const int out0 = s_out0;
     constexpr uint32_t START = (1u << 20) - 1u;
-    // a window of four run records (the voxel's runs are a prefix of it); the first window of a lane's NEXT voxel is fetched
-    // while the current voxel is summed (a wave takes the tile's voxels 64 at a time, 256 apart)
-    struct Win { int e; uint32_t key, k0, k1, k2, k3, v0, v1, v2, v3; };
-    auto first_window = [&](int hh) {
-        Win W;
-        W.e = 0; W.key = 0; W.k0 = W.k1 = W.k2 = W.k3 = 0; W.v0 = W.v1 = W.v2 = W.v3 = 0;
-        if (hh < nheads) {
-            const int e = s_head[hh];
-            W.e = e;
-            W.key = k[e];
-            W.k0 = W.key; W.v0 = v[e];
-            W.k1 = W.k2 = W.k3 = ~W.key;
-            if (e + 1 < n) { W.k1 = k[e + 1]; W.v1 = v[e + 1]; }
-            if (e + 2 < n) { W.k2 = k[e + 2]; W.v2 = v[e + 2]; }
-            if (e + 3 < n) { W.k3 = k[e + 3]; W.v3 = v[e + 3]; }
-        }
-        return W;
-    };
-    Win nextw = first_window(w * WAVE + lane);
+    // a window of four run records (the voxel's runs are a prefix of it); a wave takes the tile's voxels 64 at a time, 256 apart
+    // (fetching a lane's NEXT voxel's first window ahead was measured: nothing - nine registers for a round trip that is not
+    // the bound)
     for (int h0 = w * WAVE; h0 < nheads; h0 += BLOCK) {   // (uniform per wave: ballots inside)
         const int h = h0 + lane;
         bool alive = h < nheads;
-        const Win cw = nextw;
-        nextw = first_window(h + BLOCK);
-        int e = cw.e, i = 0, cnt = 0;
-        const uint32_t key = cw.key;
-        uint32_t wk0 = cw.k0, wk1 = cw.k1, wk2 = cw.k2, wk3 = cw.k3, wv0 = cw.v0, wv1 = cw.v1, wv2 = cw.v2, wv3 = cw.v3;
+        int e = 0, i = 0, cnt = 0;
+        uint32_t key = 0, wk0 = 0, wk1 = 0, wk2 = 0, wk3 = 0, wv0 = 0, wv1 = 0, wv2 = 0, wv3 = 0;
+        if (alive) {
+            e = s_head[h];
+            key = k[e];
+            wk0 = key; wv0 = v[e];
+            wk1 = wk2 = wk3 = ~key;
+            if (e + 1 < n) { wk1 = k[e + 1]; wv1 = v[e + 1]; }
+            if (e + 2 < n) { wk2 = k[e + 2]; wv2 = v[e + 2]; }
+            if (e + 3 < n) { wk3 = k[e + 3]; wv3 = v[e + 3]; }
+        }
         uint32_t nk0 = 0, nk1 = 0, nk2 = 0, nk3 = 0, nv0 = 0, nv1 = 0, nv2 = 0, nv3 = 0;
         float sx = 0.f, sy = 0.f, sz = 0.f;
         uint32_t ir = 0, ig = 0, ib = 0;

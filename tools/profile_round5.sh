@@ -24,7 +24,7 @@ python3 $R/tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE /tmp/pmc_WRITE_SIZE $OUT/pmc
 : > $OUT/pmc_icp.txt
 : > $OUT/pmc_icp_inflight_shape.txt
 PASSES=("SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INST_CYCLES_SALU SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" "SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC" "SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_INSTS_SMEM SQ_WAVES")
-# two sets: the launch shape of a call that has the GPU to itself (1 cluster x 4 waves per workgroup: what the one-batch run picks by
+# two sets: the launch shape of a call that has the GPU to itself (1 cluster x 8 waves per workgroup for the 522 clusters of the bench batch: what the one-batch run picks by
 # itself) and the shape the launches of the timed region have (4 clusters x 2 waves, forced here; counters serialise the kernels,
 # so "under load" can only mean the shape)
 for set in "excl:" "inflight:CUBOID_LAT_SHAPE=4,2"; do
