@@ -627,7 +627,7 @@ def templates_small():
     return T.template_xyz32(length=0.2, width=0.075, height=0.1, density=0.005)
 
 
-@pytest.mark.parametrize("path", ["crop_runs", "runs", "points", "runs_off_for_big_contexts"])
+@pytest.mark.parametrize("path", ["crop_runs", "crop_runs_copy", "crop_runs_quads", "runs", "points", "runs_off_for_big_contexts"])
 def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
     """S1 sorts RUNS of equal voxel index among the cropped points.  Default since round 4 ("crop_runs"): the crop itself
     writes the runs and their digit histograms and the sort runs on the packed cell keys, only over the digits that vary
@@ -635,7 +635,14 @@ def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
     runs (rounds 2-3); CUBOID_VOXEL_RUNS=0 sorts the points (k_radix_ghist, k_voxel_centroid), and so does a context of more
     than 2^20 points per frame (a run's start has 20 bits).  Same bits as the oracle either way, on: organised frames (runs of
     ~2.4 points), one voxel holding 3000 consecutive points (runs are cut at every 64), keys that alternate from point to
-    point (every run is one point long), an unorganised cloud with rgb, frames in a batch."""
+    point (every run is one point long), an unorganised cloud with rgb, frames in a batch.
+    End of round 5: 16-byte records are left in place (run records point into the input) and the centroids are summed one lane
+    per voxel; "crop_runs_copy" (CUBOID_CROP_DIRECT=0) compacts the kept points as before, "crop_runs_quads"
+    (CUBOID_CENTROID_LANES=0) is the quad-per-voxel kernel of rounds 3-5; a 32-byte record layout (below) always takes the copy."""
+    if path == "crop_runs_copy":
+        monkeypatch.setenv("CUBOID_CROP_DIRECT", "0")
+    if path == "crop_runs_quads":
+        monkeypatch.setenv("CUBOID_CENTROID_LANES", "0")
     if path == "points":
         monkeypatch.setenv("CUBOID_VOXEL_RUNS", "0")
     if path == "runs":
@@ -661,6 +668,16 @@ def test_voxel_stage_by_runs_and_by_points(O, frames4, path, monkeypatch):
         for pts in clouds:
             vox, rgb, nc = cx.crop_voxel(pts, prm, want_rgb=True)
             st, vo, ro, nco, _ = O.crop_voxel(pts, prm, want_rgb=True)
+            assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
+        if path.startswith("crop_runs"):
+            # PointXYZRGB's layout (32-byte records, rgb at offset 16): never the in-place form
+            wide = np.zeros((len(clouds[0]), 8), np.float32)
+            wide[:, :3] = clouds[0][:, :3]
+            wide[:, 4] = clouds[0][:, 3]
+            prm32 = capi.default_params()
+            prm32.rgb_offset = 16
+            vox, rgb, nc = cx.crop_voxel(wide, prm32, want_rgb=True)
+            st, vo, ro, nco, _ = O.crop_voxel(clouds[0], prm, want_rgb=True)
             assert nc == nco and np.array_equal(vox.view(np.uint32), vo.view(np.uint32)) and np.array_equal(rgb, ro)
         if path != "runs_off_for_big_contexts":
             from perception_amd import templates
