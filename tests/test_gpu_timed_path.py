@@ -217,3 +217,32 @@ def test_pipe_big_handover_of_running_clusters(O, monkeypatch):
             ctx.close()
     assert got["0"][1] == 0 and got["1"][1] > 0, "no cluster changed workgroup"
     assert np.array_equal(got["0"][0], got["1"][0])
+
+
+@pytest.mark.parametrize("switch", ["CUBOID_COPY_KERNELS", "CUBOID_ZERO_ONCE", "CUBOID_CROP_DIRECT", "CUBOID_CENTROID_LANES"])
+def test_plumbing_switches_leave_the_records_unchanged(template, switch, monkeypatch):
+    """Round 5 moved the small pinned <-> device transfers from hipMemcpyAsync to copy kernels on the context's stream (batched:
+    one launch per stage), all zero fills of a fused call into one launch, the cropped points out of the arena (run records point
+    into the input) and the centroid sums onto one lane per voxel.  Each has a switch back to the previous form: the records of a
+    fused batch call must be the same bytes either way (the default form is compared with the oracle by every other test)."""
+    F = 6
+    frames = _render(40, F)
+    prm = capi.default_params()
+    prm.rgb_offset = 12
+
+    def run():
+        ctx = capi.Context(max_points=frames.shape[1], max_frames=F)
+        try:
+            ctx.set_template(0, template)
+            res, plane_idx, labels = ctx.process_batch(frames, prm, want_indices=True)
+            return (capi.results_to_array(res).copy(), [plane_idx[f, :res[f].n_plane].copy() for f in range(F)],
+                    [labels[f, :res[f].n_objects].copy() for f in range(F)])
+        finally:
+            ctx.close()
+
+    a = run()
+    monkeypatch.setenv(switch, "0")     # (read when a context is created)
+    b = run()
+    assert np.array_equal(a[0], b[0])
+    for x, y in zip(a[1] + a[2], b[1] + b[2]):
+        assert np.array_equal(x, y)
