@@ -80,6 +80,7 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    int cluster_cells = 1;                                        // CUBOID_CLUSTER_CELLS=0: frames above 8192 object points straight to the point-graph kernels (rounds 1-5)
     int crop_direct = 1;                                          // CUBOID_CROP_DIRECT=0: the crop always copies the kept points (rounds 1-5)
     int centroid_lanes = 1;                                       // CUBOID_CENTROID_LANES=0: the quad-per-voxel centroid kernel (rounds 3-5) instead of a lane per voxel
     bool voxel_runs = true;                                       // CUBOID_VOXEL_RUNS=0: S1 sorts the cropped points instead of their runs of equal voxel index
@@ -600,8 +601,15 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint, boo
         const float small_cell = (float)(p->cluster_tolerance / std::sqrt(3.0) * (1.0 - 1.0 / 1024.0));
         LAUNCH(c, launch_cluster_lds(c->stream, c->d_obj, c->N, F, c->d_fs, 1.0f / small_cell, r2, c->d_parent, c->d_csize, c->d_rank));
     }
-    if (p->cluster_enable && (max_no_hint > 8192 || force_global)) {
-        // ... larger ones (and the rare frame the LDS kernel gave up on, fs.cl_done == 0) by the global-memory path
+    const bool by_cells = c->cluster_cells && !force_global;
+    if (p->cluster_enable && max_no_hint > 8192 && by_cells) {
+        // ... larger ones by the same cell graph with the points in global memory (k_cluster_cells; d_src is free until the labels
+        // are scattered) ...
+        const float small_cell = (float)(p->cluster_tolerance / std::sqrt(3.0) * (1.0 - 1.0 / 1024.0));
+        LAUNCH(c, launch_cluster_cells(c->stream, c->d_obj, c->N, F, c->d_fs, 1.0f / small_cell, r2, c->d_parent, c->d_csize, c->d_rank, c->d_src));
+    }
+    if (p->cluster_enable && ((max_no_hint > 8192 && !by_cells) || force_global)) {
+        // ... and the rare frame whose cells do not fit the table (fs.cl_done == 0) by the point-graph kernels in global memory
         HIPCHK(c, hipMemsetAsync(c->d_head, 0xff, sizeof(int) * (size_t)F * CELL_BUCKETS, c->stream));
         LAUNCH(c, launch_cluster_build(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, c->d_head, c->d_next, c->d_parent, c->d_csize, c->d_rank));
         LAUNCH(c, launch_cluster_hook(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, r2, c->d_head, c->d_next, c->d_parent));
@@ -621,7 +629,7 @@ int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
     int st = stage_cluster(c, F, p, max_no);
     if (st) return st;
     st = sync_fs(c, F);
-    if (st || !p->cluster_enable || max_no > 8192) return st;
+    if (st || !p->cluster_enable || (max_no > 8192 && !c->cluster_cells)) return st;   // (the point-graph kernels were part of the launch)
     bool left = false;
     for (int f = 0; f < F; ++f) left = left || (c->h_fs[f].n_o > 0 && !c->h_fs[f].cl_done);
     if (!left) return CD_OK;
@@ -1564,6 +1572,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_VOXEL_RUNS")) c->voxel_runs = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_CENTROID_LANES")) c->centroid_lanes = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_CROP_DIRECT")) c->crop_direct = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_CLUSTER_CELLS")) c->cluster_cells = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

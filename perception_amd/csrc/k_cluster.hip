@@ -404,6 +404,152 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_lds(const float4* __rest
     CL_PHASE(2)
 }
 
+// ---- the same for frames of MORE than CL_LDS_CAP object points (end of round 5): cells in LDS, points in global memory --------
+// BASELINE config 5 (five cuboids in a 1 M-point frame: ~12 k object points) and the object launch values (leaf 0.001: ~18 k) put
+// every frame beyond what k_cluster_lds holds, and the point-graph kernels below it (k_cluster_build / hook / flatten: linked
+// lists and a union-find over POINTS in HBM) took 1.7 ms per 64 such frames.  The number of CELLS does not grow with the
+// density, so the cell table, the cell counts and the union-find over cells still fit LDS; only the points move out: they are
+// put in cell order into `sorted` (a per-frame scratch array: the ICP source buffer, which is written after this stage), each
+// point's (slot, ticket) waits in parent / csize, which receive their final values at the end.  Same cells, same predicate,
+// same components as k_cluster_lds.  Frames the table cannot hold keep cl_done = 0 for the point-graph kernels.
+__device__ __forceinline__ void cl_join_g(const int* s_key, const int* s_val, int* s_par, const float4* __restrict__ S, int ha, int key, int delta,
+                                          float r2, int& ra) {
+    const int hb = cl_lookup(s_key, key + delta);
+    if (hb < 0) return;
+    int rb = lds_find(s_par, hb);
+    if (rb == ra) return;
+    const int a0 = s_val[ha], a1 = s_val[ha + 1], b0 = s_val[hb], b1 = s_val[hb + 1];
+    bool hit = false;
+    for (int a = a0; a < a1 && !hit; ++a) {
+        const float4 p = S[a];
+        for (int b = b0; b < b1; b += 4) {   // four candidates per trip, their loads in flight together (the last one repeats at the end)
+            const float4 q0 = S[b], q1 = S[min(b + 1, b1 - 1)], q2 = S[min(b + 2, b1 - 1)], q3 = S[min(b + 3, b1 - 1)];
+            const float d0 = dist2(p.x, p.y, p.z, q0.x, q0.y, q0.z), d1 = dist2(p.x, p.y, p.z, q1.x, q1.y, q1.z);
+            const float d2 = dist2(p.x, p.y, p.z, q2.x, q2.y, q2.z), d3 = dist2(p.x, p.y, p.z, q3.x, q3.y, q3.z);
+            if (d0 < r2 || d1 < r2 || d2 < r2 || d3 < r2) { hit = true; break; }
+        }
+    }
+    if (!hit) return;
+    ra = lds_find(s_par, ra);
+    rb = lds_find(s_par, rb);
+    while (ra != rb) {
+        const int big = ra > rb ? ra : rb, sml = ra > rb ? rb : ra;
+        const int old = atomicCAS(&s_par[big], big, sml);
+        if (old == big) { ra = sml; break; }
+        ra = lds_find(s_par, ra);
+        rb = lds_find(s_par, rb);
+    }
+}
+
+__global__ void __launch_bounds__(CL_THREADS) k_cluster_cells(const float4* __restrict__ obj, int N, FrameState* __restrict__ fs,
+                                                              float inv_cell, float r2, int* __restrict__ parent,
+                                                              int* __restrict__ csize, int* __restrict__ rank_of_root,
+                                                              float4* __restrict__ sorted) {
+    CD_FRONT_PRIO();
+    __shared__ int s_key[CL_SLOTS];        // packed cell of the slot, -1 = empty; after the hook: per-component smallest member
+    __shared__ int s_val[CL_SLOTS + 1];    // points in the slot's cell, then their start; after the hook: per-component size
+    __shared__ int s_par[CL_SLOTS];        // union-find over slots
+    __shared__ unsigned short s_cells[CL_MAX_CELLS];
+    __shared__ int s_w[CL_WAVES];
+    __shared__ int s_ncell, s_bail;
+    const int f = blockIdx.x;
+    const int n = fs[f].n_o;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    if (n <= 0 || fs[f].cl_done) return;       // (uniform) empty, or finished by k_cluster_lds
+    const size_t fbase = (size_t)f * N;
+    const float4* __restrict__ P = obj + fbase;
+    float4* __restrict__ S = sorted + fbase;
+    int* slot_of = parent + fbase;             // scratch until the end
+    int* ticket_of = csize + fbase;
+    const float org[3] = {fs[f].origin[0], fs[f].origin[1], fs[f].origin[2]};
+    for (int i = tid; i < CL_SLOTS; i += CL_THREADS) { s_key[i] = -1; s_val[i] = 0; s_par[i] = i; }
+    if (tid == 0) { s_ncell = 0; s_bail = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += CL_THREADS) {
+        int cx, cy, cz;
+        cell_of(P[i], org, inv_cell, cx, cy, cz);
+        bool ok = cx >= CL_COORD_MIN && cy >= CL_COORD_MIN && cz >= CL_COORD_MIN && cx <= CL_COORD_MAX && cy <= CL_COORD_MAX && cz <= CL_COORD_MAX;
+        int h = 0, tk = 0;
+        if (ok) {
+            const int key = (cx + 3) | ((cy + 3) << 10) | ((cz + 3) << 20);
+            h = (int)cl_slot_hash(key);
+            ok = false;
+            for (int probe = 0; probe < CL_SLOTS; ++probe) {
+                const int old = atomicCAS(&s_key[h], -1, key);
+                if (old == -1) {
+                    const int ci = atomicAdd(&s_ncell, 1);
+                    if (ci < CL_MAX_CELLS) s_cells[ci] = (unsigned short)h;
+                    ok = true;
+                    break;
+                }
+                if (old == key) { ok = true; break; }
+                h = (h + 1) & (CL_SLOTS - 1);
+            }
+            if (ok) tk = atomicAdd(&s_val[h], 1);
+        }
+        if (!ok) s_bail = 1;
+        slot_of[i] = h;
+        ticket_of[i] = tk;
+    }
+    __syncthreads();
+    const int ncell = s_ncell;
+    if (s_bail || ncell > CL_MAX_CELLS) return;   // (uniform) cl_done stays 0: the point-graph kernels take the frame
+    {   // exclusive scan of the slot counts: four consecutive slots per thread
+        const int q = 4 * tid;
+        const int c0 = s_val[q], c1 = s_val[q + 1], c2 = s_val[q + 2], c3 = s_val[q + 3];
+        const int sum = c0 + c1 + c2 + c3;
+        int inc = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int u = __shfl_up(inc, o, 64);
+            if (lane >= o) inc += u;
+        }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        int base = inc - sum;
+        for (int v = 0; v < w; ++v) base += s_w[v];
+        s_val[q] = base;
+        s_val[q + 1] = base + c0;
+        s_val[q + 2] = base + c0 + c1;
+        s_val[q + 3] = base + c0 + c1 + c2;
+        if (tid == 0) s_val[CL_SLOTS] = n;
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CL_THREADS) S[s_val[slot_of[i]] + ticket_of[i]] = P[i];   // (every thread reads back its own words)
+    __syncthreads();   // (workgroup-scope release / acquire: the points are read by other waves of this workgroup below)
+    const int items = ncell * CL_LANES_PER_CELL;
+    for (int ring = 0; ring < 2; ++ring) {
+        const int j0 = ring == 0 ? 0 : CL_RING1, j1 = ring == 0 ? CL_RING1 : CL_FORWARD;
+        for (int it = tid; it < items; it += CL_THREADS) {
+            const int ha = (int)s_cells[it / CL_LANES_PER_CELL], g = it % CL_LANES_PER_CELL;
+            const int key = s_key[ha];
+            int ra = lds_find(s_par, ha);
+#pragma unroll 1
+            for (int j = j0 + g; j < j1; j += CL_LANES_PER_CELL) cl_join_g(s_key, s_val, s_par, S, ha, key, cl_offsets.d[j], r2, ra);
+        }
+        __syncthreads();
+    }
+    int* s_min = s_key;   // (the keys and the cell starts are dead from here on)
+    int* s_cnt = s_val;
+    for (int q = tid; q < CL_SLOTS; q += CL_THREADS) { s_min[q] = 0x7fffffff; s_cnt[q] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n; i += CL_THREADS) {
+        const int r = lds_find(s_par, slot_of[i]);
+        slot_of[i] = r;
+        atomicMin(&s_min[r], i);
+        atomicAdd(&s_cnt[r], 1);
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += CL_THREADS) {
+        const int root = slot_of[i];
+        const int r = s_min[root];
+        parent[fbase + i] = r;
+        csize[fbase + i] = r == i ? s_cnt[root] : 0;
+        rank_of_root[fbase + i] = -1;
+    }
+    if (tid == 0) fs[f].cl_done = 1;
+}
+
 // one block per frame
 __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __restrict__ fs, int enable, int min_sz,
                                                         int max_sz, const int* __restrict__ parent,
@@ -577,6 +723,10 @@ static inline int grid_for(int n_max) {
 void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
                         int* parent, int* csize, int* rank_of_root) {
     hipLaunchKernelGGL(k_cluster_lds, dim3(F), dim3(CL_THREADS), 0, s, obj, N, fs, inv_cell, r2, parent, csize, rank_of_root);
+}
+void launch_cluster_cells(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
+                          int* parent, int* csize, int* rank_of_root, float4* sorted) {
+    hipLaunchKernelGGL(k_cluster_cells, dim3(F), dim3(CL_THREADS), 0, s, obj, N, fs, inv_cell, r2, parent, csize, rank_of_root, sorted);
 }
 void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
                           int* head, int* next, int* parent, int* csize, int* rank_of_root) {

@@ -62,6 +62,8 @@ void launch_extract_scatter(hipStream_t s, const float4* vox, int N, int F, int 
 // k_cluster.hip
 void launch_cluster_lds(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
                         int* parent, int* csize, int* rank_of_root);
+void launch_cluster_cells(hipStream_t s, const float4* obj, int N, int F, FrameState* fs, float inv_cell, float r2,
+                          int* parent, int* csize, int* rank_of_root, float4* sorted);
 void launch_cluster_build(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,
                           int* head, int* next, int* parent, int* csize, int* rank_of_root);
 void launch_cluster_hook(hipStream_t s, const float4* obj, int N, int F, int Tact, const FrameState* fs, float inv_cell,

@@ -267,6 +267,44 @@ def test_cluster_cell_kernel_edges(ctx, O):
         assert np.array_equal(sizes, s0), name
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("cells", ["1", "0"])
+def test_cluster_beyond_the_lds_capacity(O, cells, monkeypatch):
+    """Frames of more than 8192 object points (BASELINE config 5, the object launch values): the cell graph with the cells in
+    LDS and the points in global memory (k_cluster_cells, end of round 5); CUBOID_CLUSTER_CELLS=0: the point-graph kernels of
+    rounds 1-5.  Dense blobs and slabs (few cells, hundreds of points per cell), exact-tie distances, a cloud whose cells do
+    not fit the table (falls through to the point-graph kernels either way), components beyond the size window - labels and
+    sizes identical to the oracle."""
+    monkeypatch.setenv("CUBOID_CLUSTER_CELLS", cells)
+    cx = capi.Context(max_points=70000, max_frames=1)
+    try:
+        prm = capi.default_params()
+        prm.cluster_min_size, prm.cluster_max_size = 1, 25000
+        rng = np.random.RandomState(23)
+        cases = {}
+        cases["dense_blobs"] = np.concatenate([_blob([0, 0, .5], 9000, .03, rng), _blob([.3, 0, .5], 6000, .02, rng),
+                                               _blob([.3, .2, .6], 3000, .005, rng), rng.uniform(-0.5, 0.5, (400, 3)).astype(np.float32)])
+        cases["slab"] = (rng.uniform(0, 1, (20000, 3)) * [0.5, 0.4, 0.02]).astype(np.float32)
+        q = rng.randint(0, 48, (40000, 3)).astype(np.float32) * np.float32(0.0025)     # exact ties at 0.02 (strict <)
+        cases["lattice"] = np.unique(q, axis=0)[:30000]
+        cases["too_many_cells"] = np.concatenate([_blob([0, 0, .5], 2000, .01, rng), rng.uniform(-1.5, 1.5, (9000, 3)).astype(np.float32)])
+        cases["oversize_component"] = (rng.uniform(0, 1, (26000, 3)) * [0.3, 0.3, 0.01]).astype(np.float32)
+        for name, pts in cases.items():
+            pts = np.ascontiguousarray(pts[rng.permutation(len(pts))], np.float32)
+            assert len(pts) > 8192
+            lab, sizes, k = cx.cluster(pts, prm, sizes_capacity=16384)
+            l0, s0, k0 = O.cluster(pts, prm, mode=1, sizes_capacity=16384)
+            assert k == k0, (name, k, k0)
+            assert np.array_equal(lab, l0), name
+            assert np.array_equal(sizes, s0), name
+        prm.cluster_min_size = 200      # the launch value: small components dropped
+        lab, sizes, k = cx.cluster(cases["dense_blobs"], prm, sizes_capacity=16384)
+        l0, s0, k0 = O.cluster(cases["dense_blobs"], prm, mode=1, sizes_capacity=16384)
+        assert k == k0 and np.array_equal(lab, l0) and np.array_equal(sizes, s0)
+    finally:
+        cx.close()
+
+
 def test_icp_bit_exact_and_known_answer(ctx, O, template, frames4):
     prm = capi.default_params()
     r = O.process_frame(frames4[0], prm, template, want_clouds=True)
