@@ -80,6 +80,7 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    int mirror_writes = 1;                                        // CUBOID_MIRROR_WRITES=0: every host read-back of the FrameState array is a copy launch again
     int cluster_cells = 1;                                        // CUBOID_CLUSTER_CELLS=0: frames above 8192 object points straight to the point-graph kernels (rounds 1-5)
     int crop_direct = 1;                                          // CUBOID_CROP_DIRECT=0: the crop always copies the kept points (rounds 1-5)
     int centroid_lanes = 1;                                       // CUBOID_CENTROID_LANES=0: the quad-per-voxel centroid kernel (rounds 3-5) instead of a lane per voxel
@@ -396,6 +397,9 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // (the ticket counters reset themselves at the end of every launch that uses them; zeroed here too so that a call that
     // failed half way can never leave the next one with a counter that is not zero)
     ZERO_FILL(c, c->d_ticket, sizeof(int) * (size_t)F * TICKET_PITCH);
+    // (kernels write the pinned mirror of the FrameState array themselves where a whole copy launch used to follow them:
+    // CUBOID_MIRROR_WRITES=0 restores the copies)
+    FrameState* const fs_mirror = c->mirror_writes && c->copy_kernels ? c->h_fs : nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
         HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice));
         // (the rare redo, and the crops that use d_tileA themselves: from here on every stage fills its own arrays again)
@@ -406,17 +410,17 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
             ZERO_FILL(c, c->d_ghist, sizeof(uint32_t) * (size_t)F * SORT_MAX_PASSES_HOST * RADIX);
             LAUNCH(c, launch_crop_runs(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tile64, c->d_cpt, c->d_key[0], c->d_val[0],
                              c->d_ghist, c->d_ticket, direct_pts ? 1 : 0));
-            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, c->d_ghist));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, c->d_ghist, fs_mirror));
         } else if (kp.enabled) {
             LAUNCH(c, launch_crop_fused(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, kp, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0], c->d_ticket));
-            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, nullptr, fs_mirror));
         } else {
             LAUNCH(c, launch_crop_count(c->stream, d_in, stride, N, F, rgb_off, lim, T, c->d_fs, c->d_tileA));
             LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_c), FS_PITCH));
-            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size));
+            LAUNCH(c, launch_voxel_setup(c->stream, c->d_fs, F, p->leaf_size, nullptr, fs_mirror));
             LAUNCH(c, launch_crop_compact(c->stream, d_in, stride, N, c->N, F, rgb_off, lim, T, p->leaf_size, c->d_fs, c->d_tileA, c->d_cpt, c->d_key[0]));
         }
-        st = sync_fs(c, F);   // sync #1: n_c, key_bits (sort pass count)
+        st = sync_fs(c, F, fs_mirror != nullptr);   // sync #1: n_c, key_bits (sort pass count); the mirror was written by k_voxel_setup
         if (st) return st;
         bool over = false;
         for (int f = 0; f < F; ++f) over = over || c->h_fs[f].crop_overflow != 0;
@@ -615,7 +619,7 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint, boo
         LAUNCH(c, launch_cluster_hook(c->stream, c->d_obj, c->N, F, To, c->d_fs, inv_cell, r2, c->d_head, c->d_next, c->d_parent));
         LAUNCH(c, launch_cluster_flatten(c->stream, c->N, F, To, c->d_fs, c->d_parent, c->d_csize));
     }
-    LAUNCH(c, launch_cluster_rank(c->stream, c->N, F, c->d_fs, p->cluster_enable, p->cluster_min_size, p->cluster_max_size, c->d_parent, c->d_csize, c->d_cand, c->d_rank, c->d_sizes));
+    LAUNCH(c, launch_cluster_rank(c->stream, c->N, F, c->d_fs, p->cluster_enable, p->cluster_min_size, p->cluster_max_size, c->d_parent, c->d_csize, c->d_cand, c->d_rank, c->d_sizes, c->mirror_writes && c->copy_kernels ? c->h_fs : nullptr));
     ZERO_FILL(c, c->d_tileK, sizeof(int) * (size_t)F * KICP * T);
     LAUNCH(c, launch_label_count(c->stream, c->N, F, T, To, c->d_fs, p->cluster_enable, c->d_parent, c->d_rank, c->d_label, c->d_tileK, 0));
     LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileK, F * KICP, T, nullptr, 0));
@@ -626,9 +630,10 @@ int stage_cluster(cd_context* c, int F, const cd_params* p, int max_no_hint, boo
 // stage_cluster + sync; when the LDS kernel gave a frame up (too many cells / too wide a cloud for its table) and the
 // global-memory kernels were not part of the launch, the stage is run again with them.
 int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
+    const bool mirrored = c->mirror_writes && c->copy_kernels;   // (k_cluster_rank wrote the FrameState mirror)
     int st = stage_cluster(c, F, p, max_no);
     if (st) return st;
-    st = sync_fs(c, F);
+    st = sync_fs(c, F, mirrored);
     if (st || !p->cluster_enable || (max_no > 8192 && !c->cluster_cells)) return st;   // (the point-graph kernels were part of the launch)
     bool left = false;
     for (int f = 0; f < F; ++f) left = left || (c->h_fs[f].n_o > 0 && !c->h_fs[f].cl_done);
@@ -637,7 +642,7 @@ int stage_cluster_sync(cd_context* c, int F, const cd_params* p, int max_no) {
     c->batch_zeroed = false;   // (d_tileK has been used: the redo fills it again)
     st = stage_cluster(c, F, p, max_no, true);
     if (st) return st;
-    return sync_fs(c, F);
+    return sync_fs(c, F, mirrored);
 }
 
 // S6.  clusters described by h_cl[0..ncl) (src_off relative to d_src/d_src0).  Fills h_st / h_accf.
@@ -1573,6 +1578,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_CENTROID_LANES")) c->centroid_lanes = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_CROP_DIRECT")) c->crop_direct = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_CLUSTER_CELLS")) c->cluster_cells = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_MIRROR_WRITES")) c->mirror_writes = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

@@ -554,7 +554,10 @@ __global__ void __launch_bounds__(CL_THREADS) k_cluster_cells(const float4* __re
 __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __restrict__ fs, int enable, int min_sz,
                                                         int max_sz, const int* __restrict__ parent,
                                                         const int* __restrict__ csize, int* __restrict__ cand,
-                                                        int* __restrict__ rank_of_root, int* __restrict__ sizes_sorted) {
+                                                        int* __restrict__ rank_of_root, int* __restrict__ sizes_sorted,
+                                                        FrameState* __restrict__ mirror) {
+    // mirror != nullptr: the frame's FrameState goes to the host's pinned copy from here (the last kernel of the stage that
+    // writes it), instead of by a copy launch
     CD_FRONT_PRIO();
     __shared__ int s_w[WAVES_PER_BLOCK];
     const int f = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -566,6 +569,10 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __res
             fs[f].n_k = n > 0 ? 1 : 0;
             fs[f].ksize[0] = n;
             if (n > 0) sizes_sorted[fbase] = n;
+        }
+        if (mirror) {
+            __syncthreads();
+            if (threadIdx.x == 0) mirror[f] = fs[f];
         }
         return;
     }
@@ -608,6 +615,7 @@ __global__ void __launch_bounds__(BLOCK) k_cluster_rank(int N, FrameState* __res
         fs[f].n_k = K;
         int off = 0;
         for (int k = 0; k < KICP; ++k) { fs[f].koff[k] = off; off += fs[f].ksize[k]; }
+        if (mirror) mirror[f] = fs[f];
     }
 }
 
@@ -742,9 +750,9 @@ void launch_cluster_flatten(hipStream_t s, int N, int F, int Tact, const FrameSt
     hipLaunchKernelGGL(k_cluster_flatten, dim3(grid_for(Tact * TILE), F), dim3(BLOCK), 0, s, N, fs, parent, csize);
 }
 void launch_cluster_rank(hipStream_t s, int N, int F, FrameState* fs, int enable, int min_sz, int max_sz,
-                         const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted) {
+                         const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted, FrameState* mirror) {
     hipLaunchKernelGGL(k_cluster_rank, dim3(F), dim3(BLOCK), 0, s, N, fs, enable, min_sz, max_sz, parent, csize, cand,
-                       rank_of_root, sizes_sorted);
+                       rank_of_root, sizes_sorted, mirror);
 }
 void launch_label_count(hipStream_t s, int N, int F, int T, int Tact, const FrameState* fs, int enable, const int* parent,
                         const int* rank_of_root, int* label, int* tile_cnt, int kbase) {

@@ -140,22 +140,10 @@ __global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, 
 // ---- voxel grid geometry from the min/max (VoxelGrid::applyFilter prologue) ------------
 // after k_crop_runs: digit d of the packed cell keys varies in a frame when its histogram has two non-empty bins.  One wave per
 // frame, four coalesced 256-byte reads per digit.
-__global__ void __launch_bounds__(WAVE) k_digit_vary(FrameState* __restrict__ fs, const uint32_t* __restrict__ ghist) {
-    CD_FRONT_PRIO();
-    const int f = blockIdx.x, lane = threadIdx.x;
-    int vary = 0;
-    for (int d = 0; d < 4; ++d) {
-        int bins = 0;
-        for (int q = 0; q < RADIX / WAVE; ++q) bins += __popcll(__ballot(ghist[((size_t)f * 4 + d) * RADIX + q * WAVE + lane] != 0u));
-        if (bins > 1) vary |= 1 << d;
-    }
-    if (lane == 0) fs[f].digit_vary = vary;
-}
-__global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
-    CD_FRONT_PRIO();
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= F) return;
-    FrameState& s = fs[f];
+// One wave per frame (one launch where rounds 4-5 had k_digit_vary + k_voxel_setup + the copy of the FrameState array to its
+// host mirror): the digits that vary, the grid geometry (lane 0), and - mirror != nullptr - the frame's whole FrameState
+// written to the device-visible pinned mirror the host reads after its synchronisation.
+__device__ __forceinline__ void voxel_setup_frame(FrameState& s, float leaf) {
     s.key_bits = 0;
     s.n_cropped = s.n_c;
     s.origin[0] = s.origin[1] = s.origin[2] = 0.f;
@@ -182,6 +170,25 @@ __global__ void k_voxel_setup(FrameState* __restrict__ fs, int F, float leaf) {
     int bits = 1;
     while (bits < 31 && (1ll << bits) < cells) ++bits;
     s.key_bits = bits;
+}
+__global__ void __launch_bounds__(WAVE) k_voxel_setup(FrameState* __restrict__ fs, float leaf, const uint32_t* __restrict__ ghist,
+                                                      FrameState* __restrict__ mirror) {
+    CD_FRONT_PRIO();
+    const int f = blockIdx.x, lane = threadIdx.x;
+    int vary = 0;
+    if (ghist) {   // after k_crop_runs: digit d of the packed cell keys varies in a frame when its histogram has two non-empty bins
+        for (int d = 0; d < 4; ++d) {
+            int bins = 0;
+            for (int q = 0; q < RADIX / WAVE; ++q) bins += __popcll(__ballot(ghist[((size_t)f * 4 + d) * RADIX + q * WAVE + lane] != 0u));
+            if (bins > 1) vary |= 1 << d;
+        }
+    }
+    if (lane != 0) return;
+    FrameState s = fs[f];
+    if (ghist) s.digit_vary = vary;
+    voxel_setup_frame(s, leaf);
+    fs[f] = s;
+    if (mirror) mirror[f] = s;
 }
 
 // ---- pass B: ordered compaction + voxel key -------------------------------------------
@@ -915,9 +922,8 @@ void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int 
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch) {
     hipLaunchKernelGGL(k_scan_tiles, dim3(rows), dim3(BLOCK), 0, s, counts, T, totals, total_pitch);
 }
-void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist) {
-    if (ghist) hipLaunchKernelGGL(k_digit_vary, dim3(F), dim3(WAVE), 0, s, fs, ghist);
-    hipLaunchKernelGGL(k_voxel_setup, dim3((F + 63) / 64), dim3(64), 0, s, fs, F, leaf);
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist, FrameState* mirror) {
+    hipLaunchKernelGGL(k_voxel_setup, dim3(F), dim3(WAVE), 0, s, fs, leaf, ghist, mirror);
 }
 void launch_crop_compact(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                          int T, float leaf, const FrameState* fs, const int* tile_off, float4* cpt, uint32_t* keys) {

@@ -8,7 +8,7 @@ namespace cd {
 void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
                        FrameState* fs, int* tile_cnt);
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
-void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist = nullptr);
+void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist, FrameState* mirror);   // (mirror: device-visible host copy of fs, or nullptr)
 void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                        int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket);
 void launch_crop_runs(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
@@ -70,7 +70,7 @@ void launch_cluster_hook(hipStream_t s, const float4* obj, int N, int F, int Tac
                          float r2, const int* head, const int* next, int* parent);
 void launch_cluster_flatten(hipStream_t s, int N, int F, int Tact, const FrameState* fs, int* parent, int* csize);
 void launch_cluster_rank(hipStream_t s, int N, int F, FrameState* fs, int enable, int min_sz, int max_sz,
-                         const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted);
+                         const int* parent, const int* csize, int* cand, int* rank_of_root, int* sizes_sorted, FrameState* mirror);
 void launch_label_count(hipStream_t s, int N, int F, int T, int Tact, const FrameState* fs, int enable, const int* parent,
                         const int* rank_of_root, int* label, int* tile_cnt, int kbase);
 void launch_label_scatter(hipStream_t s, const float4* obj, int N, int F, int T, int Tact, const FrameState* fs,
