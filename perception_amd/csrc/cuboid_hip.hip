@@ -80,6 +80,8 @@ struct cd_context {
     int icp_mode = 0;                                             // 0 auto, 1 sliced multi-launch, 2 whole-cluster kernel
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
+    bool fs_initialised = false;                                  // the device FrameStates hold their initial value (set by the zero launch of a fused batch call)
+    int mirror_reads = 1;                                         // CUBOID_MIRROR_READS=0: active flags and chosen plane models are uploaded before the kernels that read them
     int mirror_writes = 1;                                        // CUBOID_MIRROR_WRITES=0: every host read-back of the FrameState array is a copy launch again
     int cluster_cells = 1;                                        // CUBOID_CLUSTER_CELLS=0: frames above 8192 object points straight to the point-graph kernels (rounds 1-5)
     int crop_direct = 1;                                          // CUBOID_CROP_DIRECT=0: the crop always copies the kept points (rounds 1-5)
@@ -401,7 +403,8 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
     // CUBOID_MIRROR_WRITES=0 restores the copies)
     FrameState* const fs_mirror = c->mirror_writes && c->copy_kernels ? c->h_fs : nullptr;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice));
+        if (!(attempt == 0 && c->fs_initialised)) HIPCHK(c, xfer(c, c->d_fs, c->h_fs, sizeof(FrameState) * F, hipMemcpyHostToDevice));   // (a fused call's zero launch set them)
+        c->fs_initialised = false;
         // (the rare redo, and the crops that use d_tileA themselves: from here on every stage fills its own arrays again)
         if (attempt > 0 || !(kp.enabled && crop_runs)) c->batch_zeroed = false;
         ZERO_FILL(c, c->d_tileA, sizeof(int) * (size_t)F * T);
@@ -479,6 +482,7 @@ int stage_crop_voxel(cd_context* c, const void* d_in, size_t stride, int N, int 
 // fs.status updated for NO_MODEL, iterations per frame.
 int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iterations, int* rounds_out) {
     const int T = c->T;
+    const bool mr = c->mirror_reads != 0;
     const float thr = hm::fold_ge(p->plane_distance_threshold);
     int max_nv = 0;
     for (int f = 0; f < F; ++f) max_nv = std::max(max_nv, c->h_fs[f].n_v);
@@ -493,9 +497,12 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     for (int r = 0; r < 4; ++r) {
         const int h_target = std::min(targets[r], h_cap);
         if (h_target <= h_prev) break;
-        HIPCHK(c, xfer(c, c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice));
-        LAUNCH(c, launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, c->d_active, c->d_models, c->d_valid));
-        LAUNCH(c, launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, c->d_active, h_prev, h_target, thr, c->d_counts));
+        // (mirror reads: the kernels read the few per-frame words the host decides - active flags, chosen models - straight from
+        // the pinned host arrays, which the device sees; CUBOID_MIRROR_READS=0 uploads them first as rounds 1-5 did)
+        if (!mr) HIPCHK(c, xfer(c, c->d_active, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice));
+        const int* active_p = mr ? c->h_active : c->d_active;
+        LAUNCH(c, launch_ransac_sample(c->stream, c->d_vox, c->N, F, c->d_fs, c->d_rnd, h_target, active_p, c->d_models, c->d_valid));
+        LAUNCH(c, launch_ransac_count(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_models, c->d_valid, active_p, h_prev, h_target, thr, c->d_counts));
         // only the first h_target columns of the [F][MAX_HYP] tables are live: one strided copy each
         {   // (one launch: the three tables and - sync_fs below finds it done - nothing else; the FrameState read-back follows)
             XferBatch xb(c);
@@ -542,6 +549,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
             const float mm[4] = {c->h_model[f].x, c->h_model[f].y, c->h_model[f].z, c->h_model[f].w};
             c->h_active[f] = c->h_have[f] && hm::plane_model_valid(p->plane_model, mm, p->plane_axis, p->plane_eps_angle) ? 1 : 0;
         }
+        if (mr) return CD_OK;   // (the kernels read h_model / h_active)
         XferBatch xb(c);
         if (models_too) xb.add(c->d_model, models_too, sizeof(float4) * F, hipMemcpyHostToDevice);
         xb.add(c->d_have, c->h_active, sizeof(int) * F, hipMemcpyHostToDevice);
@@ -551,7 +559,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
     if (int st = upload_have(&c->h_model[0])) return st;   // (the chosen models ride along: one launch)
     if (p->plane_optimize) {
         ZERO_FILL(c, c->d_sums, sizeof(unsigned long long) * 10 * F);
-        LAUNCH(c, launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, c->d_model, c->d_have, thr, c->d_sums));
+        LAUNCH(c, launch_plane_cov(c->stream, c->d_vox, c->N, F, Tv, c->d_fs, mr ? c->h_model : c->d_model, mr ? c->h_active : c->d_have, thr, c->d_sums));
         HIPCHK(c, xfer(c, c->h_sums, c->d_sums, sizeof(unsigned long long) * 10 * F, hipMemcpyDeviceToHost));
         HIPCHK(c, hipStreamSynchronize(c->stream));   // sync #3
         for (int f = 0; f < F; ++f) {
@@ -560,7 +568,7 @@ int stage_plane(cd_context* c, int F, const cd_params* p, std::vector<int>& iter
             hm::plane_refit_from_moments((const uint64_t*)(c->h_sums + 10 * (size_t)f), in, out);
             c->h_model[f] = make_float4(out[0], out[1], out[2], out[3]);
         }
-        HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
+        if (!mr) HIPCHK(c, xfer(c, c->d_model, c->h_model, sizeof(float4) * F, hipMemcpyHostToDevice));
         if (p->plane_model != CD_PLANE) {
             HIPCHK(c, hipStreamSynchronize(c->stream));   // h_active is about to be rewritten
             if (int st = upload_have()) return st;
@@ -583,12 +591,18 @@ int stage_extract(cd_context* c, int F, const cd_params* p, int gate_mode = -1) 
     gate.enable = gate_mode >= 0 ? gate_mode : (p->bbox_enable ? 1 : 0);
     for (int i = 0; i < 12; ++i) gate.P[i] = p->bbox_P[i];
     for (int i = 0; i < 4; ++i) gate.rect[i] = (float)p->bbox_rect[i];
+    const float4* model_p = c->mirror_reads ? c->h_model : c->d_model;   // (see stage_plane)
+    const int* have_p = c->mirror_reads ? c->h_active : c->d_have;
     ZERO_FILL(c, c->d_tileA, sizeof(int) * (size_t)F * T);
     ZERO_FILL(c, c->d_tileB, sizeof(int) * (size_t)F * T);
-    LAUNCH(c, launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB));
-    LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileA, F, T, FS_FIELD(c, n_plane), FS_PITCH));
-    LAUNCH(c, launch_scan_tiles(c->stream, c->d_tileB, F, T, FS_FIELD(c, n_o), FS_PITCH));
-    LAUNCH(c, launch_extract_scatter(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, c->d_model, c->d_have, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB, c->d_plane_idx, c->d_obj));
+    LAUNCH(c, launch_plane_flag_count(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, model_p, have_p, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB));
+    {   // both scans in one launch; the two totals also go straight into the host's FrameState mirror (nothing else of it changes here)
+        const bool mirrored = c->mirror_writes && c->copy_kernels;
+        const ScanJob ja{c->d_tileA, FS_FIELD(c, n_plane), mirrored ? (int*)((char*)c->h_fs + offsetof(FrameState, n_plane)) : nullptr};
+        const ScanJob jb{c->d_tileB, FS_FIELD(c, n_o), mirrored ? (int*)((char*)c->h_fs + offsetof(FrameState, n_o)) : nullptr};
+        LAUNCH(c, launch_scan_tiles2(c->stream, ja, jb, F, T, FS_PITCH));
+    }
+    LAUNCH(c, launch_extract_scatter(c->stream, c->d_vox, c->N, F, T, Tv, c->d_fs, model_p, have_p, thr, p->extract_negative, p->crop2_enable, z2lo, z2hi, gate, c->d_tileA, c->d_tileB, c->d_plane_idx, c->d_obj));
     return CD_OK;
 }
 
@@ -1157,13 +1171,16 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     HIPCHK(c, hipEventRecord(c->ev[0], c->stream));
     struct ZeroedScope {   // the stages skip their own fills for the duration of this call only
         cd_context* c;
-        ~ZeroedScope() { c->batch_zeroed = false; }
+        ~ZeroedScope() { c->batch_zeroed = false; c->fs_initialised = false; }
     } zeroed_scope{c};
     if (c->zero_once) {
         // every scratch array the stages want zeroed, in ONE launch (a batch had ~14 fill kernels, each a stream operation of its
         // own that queues behind the other contexts' kernels)
         ZeroRegions zr;
         zr.n = 0;
+        zr.fs = c->mirror_writes && c->copy_kernels ? c->d_fs : nullptr;   // (the crop stage then skips its upload of the initial FrameStates)
+        zr.nfs = F;
+        c->fs_initialised = zr.fs != nullptr;
         auto add = [&](void* ptr, size_t bytes) { zr.ptr[zr.n] = (uint32_t*)ptr; zr.words[zr.n] = bytes / 4; ++zr.n; };
         const size_t FT = (size_t)F * c->T;
         add(c->d_ticket, sizeof(int) * (size_t)F * TICKET_PITCH);
@@ -1193,7 +1210,7 @@ int process_batch_impl(cd_context* c, const void* d_frames, size_t stride, int N
     HIPCHK(c, hipEventRecord(c->ev[2], c->stream));
     st = stage_extract(c, F, p);
     if (st) return st;
-    st = sync_fs(c, F);   // n_o per frame: picks the LDS / global clustering path and sizes the launches
+    st = sync_fs(c, F, c->mirror_writes && c->copy_kernels);   // n_o per frame (written to the mirror by the scan): picks the clustering path and sizes the launches
     if (st) return st;
     int max_no = 0;
     for (int f = 0; f < F; ++f) max_no = std::max(max_no, c->h_fs[f].n_o);
@@ -1579,6 +1596,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_CROP_DIRECT")) c->crop_direct = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_CLUSTER_CELLS")) c->cluster_cells = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_MIRROR_WRITES")) c->mirror_writes = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_MIRROR_READS")) c->mirror_reads = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);
@@ -2206,6 +2224,7 @@ static int cd_bbox_filter_impl(cd_context* c, const void* xyz, size_t stride, in
     for (int i = 0; i < 12; ++i) q.bbox_P[i] = P[i];
     for (int i = 0; i < 4; ++i) q.bbox_rect[i] = rect[i];
     HIPCHK(c, hipMemsetAsync(c->d_have, 0, sizeof(int), c->stream));
+    c->h_active[0] = 0;   // (no plane: with mirror reads the kernels look here; no kernel of this context is in flight)
     st = stage_extract(c, 1, &q, 2);
     if (st) return st;
     st = sync_fs(c, 1);

@@ -408,12 +408,23 @@ __global__ void __launch_bounds__(BLOCK) k_copy_rows(CopyList L) {
 // every zero-initialised scratch array of a fused batch call in ONE launch (blockIdx.y = region) instead of a dozen fill kernels
 __global__ void __launch_bounds__(BLOCK) k_zero_regions(ZeroRegions r) {
     CD_FRONT_PRIO();
+    if ((int)blockIdx.y == r.n) {   // the FrameState array's initial value: zero, mn[] = the ordered-uint encoding of +max
+        constexpr size_t W = sizeof(FrameState) / 4, MN0 = offsetof(FrameState, mn) / 4;
+        uint32_t* p = reinterpret_cast<uint32_t*>(r.fs);
+        const size_t n = W * (size_t)r.nfs;
+        for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+            const size_t w = i % W;
+            p[i] = (w >= MN0 && w < MN0 + 3) ? 0xffffffffu : 0u;
+        }
+        return;
+    }
     uint32_t* p = r.ptr[blockIdx.y];
     const size_t n = r.words[blockIdx.y];
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) p[i] = 0u;
 }
 void launch_zero_regions(hipStream_t s, const ZeroRegions& r) {
-    if (r.n > 0) hipLaunchKernelGGL(k_zero_regions, dim3(128, r.n), dim3(BLOCK), 0, s, r);
+    const int ny = r.n + (r.fs && r.nfs > 0 ? 1 : 0);
+    if (ny > 0) hipLaunchKernelGGL(k_zero_regions, dim3(128, ny), dim3(BLOCK), 0, s, r);
 }
 // several transfers in ONE launch (blockIdx.y = transfer): consecutive copies of a stage cost one stream operation
 void launch_copy_list(hipStream_t s, const CopyList& L) {

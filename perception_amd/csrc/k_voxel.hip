@@ -106,13 +106,15 @@ __global__ void __launch_bounds__(BLOCK) k_crop_count(const char* __restrict__ i
 
 // ---- per-"row" exclusive scan of tile totals (rows = frames, or frames x bins) --------
 // counts[row*T + t] -> exclusive prefix in place; total -> totals[row*total_pitch].
-__global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, int T, int* __restrict__ totals,
-                                                      int total_pitch) {
+__global__ void __launch_bounds__(BLOCK) k_scan_tiles(ScanJob j0, ScanJob j1, int T, int total_pitch) {
+    // blockIdx.y picks the job (two independent scans of a stage in one launch); a job's total per row goes to `totals` and -
+    // mirror != nullptr - to the same field of the host's pinned FrameState copy
     CD_FRONT_PRIO();
     __shared__ int s_w[WAVES_PER_BLOCK];
     __shared__ int s_base;
+    const ScanJob job = blockIdx.y ? j1 : j0;
     const int row = blockIdx.x, w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    int* c = counts + (size_t)row * T;
+    int* c = job.counts + (size_t)row * T;
     if (threadIdx.x == 0) s_base = 0;
     __syncthreads();
     for (int t0 = 0; t0 < T; t0 += BLOCK) {
@@ -134,7 +136,10 @@ __global__ void __launch_bounds__(BLOCK) k_scan_tiles(int* __restrict__ counts, 
         if (threadIdx.x == BLOCK - 1) s_base = base + wb + inc;
         __syncthreads();
     }
-    if (threadIdx.x == 0 && totals) totals[(size_t)row * total_pitch] = s_base;
+    if (threadIdx.x == 0) {
+        if (job.totals) job.totals[(size_t)row * total_pitch] = s_base;
+        if (job.mirror) job.mirror[(size_t)row * total_pitch] = s_base;
+    }
 }
 
 // ---- voxel grid geometry from the min/max (VoxelGrid::applyFilter prologue) ------------
@@ -920,7 +925,11 @@ void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int 
     hipLaunchKernelGGL(k_crop_count, dim3(Tin, F), dim3(BLOCK), 0, s, (const char*)in, stride, N, rgb_off, lim, T, fs, tile_cnt);
 }
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch) {
-    hipLaunchKernelGGL(k_scan_tiles, dim3(rows), dim3(BLOCK), 0, s, counts, T, totals, total_pitch);
+    const ScanJob j{counts, totals, nullptr};
+    hipLaunchKernelGGL(k_scan_tiles, dim3(rows, 1), dim3(BLOCK), 0, s, j, j, T, total_pitch);
+}
+void launch_scan_tiles2(hipStream_t s, const ScanJob& a, const ScanJob& b, int rows, int T, int total_pitch) {
+    hipLaunchKernelGGL(k_scan_tiles, dim3(rows, 2), dim3(BLOCK), 0, s, a, b, T, total_pitch);
 }
 void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist, FrameState* mirror) {
     hipLaunchKernelGGL(k_voxel_setup, dim3(F), dim3(WAVE), 0, s, fs, leaf, ghist, mirror);

@@ -7,7 +7,9 @@ namespace cd {
 // k_voxel.hip
 void launch_crop_count(hipStream_t s, const void* in, size_t stride, int N, int F, int rgb_off, CropLimits lim, int T,
                        FrameState* fs, int* tile_cnt);
+struct ScanJob { int* counts; int* totals; int* mirror; };   // exclusive scan of counts[row][0..T) in place, row totals to totals / mirror[row * pitch]
 void launch_scan_tiles(hipStream_t s, int* counts, int rows, int T, int* totals, int total_pitch);
+void launch_scan_tiles2(hipStream_t s, const ScanJob& a, const ScanJob& b, int rows, int T, int total_pitch);   // two scans, one launch
 void launch_voxel_setup(hipStream_t s, FrameState* fs, int F, float leaf, const uint32_t* ghist, FrameState* mirror);   // (mirror: device-visible host copy of fs, or nullptr)
 void launch_crop_fused(hipStream_t s, const void* in, size_t stride, int N, int pitch, int F, int rgb_off, CropLimits lim,
                        int T, float leaf, KeyPack kp, FrameState* fs, int* state, float4* cpt, uint32_t* keys, int* ticket);
@@ -22,7 +24,7 @@ void launch_voxel_centroid_runs(hipStream_t s, const uint32_t* keys, const uint3
                                 int T, int Tact, int rgb_on, FrameState* fs, int* state, float4* vox, int* ticket, int lanes, int pts_pitch);
 
 void launch_mark_indices(hipStream_t s, const int* idx, int m, int n, int* flag);
-struct ZeroRegions { int n; uint32_t* ptr[16]; size_t words[16]; };
+struct ZeroRegions { int n; uint32_t* ptr[16]; size_t words[16]; FrameState* fs; int nfs; };   // fs != nullptr: nfs FrameStates set to their initial value (zero, mn = +max) as one more region
 void launch_zero_regions(hipStream_t s, const ZeroRegions& r);
 struct CopySeg { uint32_t* dst; const uint32_t* src; size_t dpitch_w, spitch_w; int width_w, rows; };   // pitches and width in 4-byte words
 struct CopyList { int n; CopySeg seg[8]; };
