@@ -81,6 +81,7 @@ struct cd_context {
     int icp_max_wg = 0;                                           // > 0: cap on the persistent ICP grid (CUBOID_ICP_MAX_WG; tests force slot refills with it)
     int icp_cpw = 0;                                              // CUBOID_ICP_CPW: clusters per workgroup a persistent ICP launch is sized for (0: by regime, stage_icp)
     bool fs_initialised = false;                                  // the device FrameStates hold their initial value (set by the zero launch of a fused batch call)
+    int icp_direct = 1;                                           // CUBOID_ICP_DIRECT=0: an all-lattice ICP stage uploads its lists and reads its results back by copy launches
     int mirror_reads = 1;                                         // CUBOID_MIRROR_READS=0: active flags and chosen plane models are uploaded before the kernels that read them
     int mirror_writes = 1;                                        // CUBOID_MIRROR_WRITES=0: every host read-back of the FrameState array is a copy launch again
     int cluster_cells = 1;                                        // CUBOID_CLUSTER_CELLS=0: frames above 8192 object points straight to the point-graph kernels (rounds 1-5)
@@ -752,7 +753,11 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
             else if (cl.n < 3) { st.done = 1; st.status = CD_ERR_FEW_CORRESPONDENCES; }
         }
     }
-    {
+    // A stage whose clusters ALL take k_icp_lat (the default template, no initial guess): the kernel reads the cluster list, the
+    // order and the initial states from the pinned host arrays and writes the final states and fitness sums there - a few
+    // hundred bytes per cluster once at each end of its ICP - instead of three copy launches around it.
+    const bool lat_direct = c->icp_direct && n_lat > 0 && n_lat == n_live && guess_mode == CD_GUESS_NONE && c->mirror_reads && c->mirror_writes && c->copy_kernels;
+    if (!lat_direct) {
         XferBatch xb(c);   // (one launch)
         xb.add(c->d_cl, c->h_cl, sizeof(IcpCluster) * ncl, hipMemcpyHostToDevice);
         if (nwork > 0) xb.add(c->d_work, c->h_work, sizeof(IcpWork) * nwork, hipMemcpyHostToDevice);
@@ -802,7 +807,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         int no = 0;
         for (int k = 0; k < ncl; ++k) if (in_lat[(size_t)k]) c->h_order[no++] = k;
         std::stable_sort(c->h_order, c->h_order + no, [&](int a, int b) { return c->h_cl[a].n > c->h_cl[b].n; });
-        HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
+        if (!lat_direct) HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
         // Shape of the launch (k_icp_lat.hip): clusters per workgroup x waves per cluster.  A call that has the GPU to itself wants
         // the launch short: one cluster per workgroup, four waves each when there are clusters enough to fill the chip twice that way,
         // eight or sixteen for fewer or very large clusters (one frame; config 5's thousands of points).  With other batches in
@@ -818,16 +823,22 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
         const int n_wg = std::max(1, (n_lat + cpw * per_slot - 1) / (cpw * per_slot));
         GateHold lat_hold;   // (CUBOID_ICP_CONCURRENT: at most that many contexts between this launch and its completion)
         if (c->icp_concurrent > 0) lat_hold.enter(&g_icp_gate[c->device & (MAX_DEVICES - 1)], c->icp_concurrent);
-        if (!pre_zeroed) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int), c->stream));   // head of the cluster queue
-        LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, ip));
+        if (!pre_zeroed) HIPCHK(c, hipMemsetAsync(c->d_queue, 0, 2 * sizeof(int), c->stream));   // head of the cluster queue, count of finished workgroups
+        if (lat_direct) std::memset(c->h_accf, 0, sizeof(unsigned long long) * ((size_t)ncl + 1));   // (what the zeroed device array used to bring back for clusters the kernel skips)
+        if (lat_direct)
+            LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->h_order, c->h_cl, c->h_st, c->h_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, c->h_accf + ncl, ip));
+        else
+            LAUNCH(c, launch_icp_lat(c->stream, n_lat, cpw, wpc, n_wg, c->d_order, c->d_cl, c->d_st, c->d_accf, c->d_lat, c->d_src, c->d_src0, c->d_queue, c->d_accf + ncl, nullptr, ip));
         c->timing.icp_kernel_launches = 1;
         c->timing.icp_regime = (cpw << 16) | std::min(n_wg, 0xffff);
         if (n_lat == n_live) {
             HIPCHK(c, hipEventRecord(c->ev[6], c->stream));
-            XferBatch xb(c);   // (one launch)
-            xb.add(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost);
-            xb.add(c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost);
-            HIPCHK(c, xb.flush());
+            if (!lat_direct) {
+                XferBatch xb(c);   // (one launch)
+                xb.add(c->h_st, c->d_st, sizeof(IcpState) * 2 * ncl, hipMemcpyDeviceToHost);
+                xb.add(c->h_accf, c->d_accf, sizeof(unsigned long long) * ((size_t)ncl + 1), hipMemcpyDeviceToHost);
+                HIPCHK(c, xb.flush());
+            }
             HIPCHK(c, hipStreamSynchronize(c->stream));
             float ms1 = 0.f;
             hipEventElapsedTime(&ms1, c->ev[5], c->ev[6]);
@@ -897,7 +908,7 @@ int stage_icp(cd_context* c, int ncl, const cd_params* p, long long* pair_tests)
                 ++gq;
             }
         }
-        HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
+        if (!lat_direct) HIPCHK(c, xfer(c, c->d_order, c->h_order, sizeof(int) * (size_t)no, hipMemcpyHostToDevice));
         HIPCHK(c, xfer(c, c->d_wgtab, tab, sizeof(int) * (size_t)ntab, hipMemcpyHostToDevice));
         HIPCHK(c, hipMemsetAsync(c->d_queue, 0, sizeof(int) * 16, c->stream));   // one queue head per group
         // the LDS-template launch goes to the context's stream (stream3 with icp_lowprio), the global-template launch beside it
@@ -1597,6 +1608,7 @@ int cd_create(int device_id, int max_points, int max_frames, cd_context** out) {
     if (const char* m = std::getenv("CUBOID_CLUSTER_CELLS")) c->cluster_cells = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_MIRROR_WRITES")) c->mirror_writes = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_MIRROR_READS")) c->mirror_reads = std::atoi(m) != 0;
+    if (const char* m = std::getenv("CUBOID_ICP_DIRECT")) c->icp_direct = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_BIG_WEIGHT")) c->icp_big_weight = std::max(0, std::atoi(m));
     if (const char* m = std::getenv("CUBOID_CROP_TWO_PASS")) c->crop_two_pass = std::atoi(m) != 0;
     if (const char* m = std::getenv("CUBOID_ICP_PERSIST")) c->icp_persist = std::atoi(m);

@@ -292,7 +292,11 @@ template <int CPW, int WPC>
 __global__ void __launch_bounds__(CPW * WPC * WAVE, CD_LAT_WAVES_PER_EU)
 k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restrict__ cl, IcpState* __restrict__ st,
           unsigned long long* __restrict__ accf, const IcpLattice* __restrict__ lats, float4* __restrict__ src,
-          const float4* __restrict__ src0, int* __restrict__ queue, unsigned long long* __restrict__ busy, IcpParams prm) {
+          const float4* __restrict__ src0, int* __restrict__ queue, unsigned long long* __restrict__ busy,
+          unsigned long long* __restrict__ busy_out, IcpParams prm) {
+    // (order / cl / st / accf may be the host's pinned arrays: every access to them is one cluster's record at a refill or at
+    // the end of its ICP.  busy_out != nullptr: the last workgroup to finish writes the launch's wave-time there - queue[1]
+    // counts the finished workgroups)
     __shared__ float4 s_tab[CPW][LAT_MAX_TAB];
     __shared__ int4 s_face[CPW][2 * LAT_MAX_FACES];
     __shared__ unsigned long long s_acc[CPW][16];
@@ -491,7 +495,16 @@ k_icp_lat(int nitems, const int* __restrict__ order, const IcpCluster* __restric
 #endif
     // the wave-time this launch cost: lifetime of the workgroup (100 MHz ticks) x its waves, summed over the workgroups
     // (cd_timing.icp_wave_ms: what a batch's ICP holds of the chip's wave slots, the throughput roof with batches in flight)
-    if (threadIdx.x == 0 && busy) atomicAdd(busy, (unsigned long long)(wall_clock64() - wg_t0) * (unsigned long long)(CPW * WPC));
+    if (threadIdx.x == 0 && busy) {
+        atomicAdd(busy, (unsigned long long)(wall_clock64() - wg_t0) * (unsigned long long)(CPW * WPC));
+        if (busy_out) {
+            __threadfence();
+            if (atomicAdd(queue + 1, 1) == (int)gridDim.x - 1) {
+                __threadfence();
+                *busy_out = atomicAdd(busy, 0ull);
+            }
+        }
+    }
 }
 
 // diagnostic / test entry: nearest template point of arbitrary queries (original index and canonical d2)
@@ -513,19 +526,21 @@ __global__ void __launch_bounds__(BLOCK) k_lat_nn(const IcpLattice* __restrict__
 // shape = clusters per workgroup * 256 + waves per cluster (1 | 2 | 4 | 8 x 1 | 2 | 4 | 8 | 16, at most 16 waves per workgroup)
 template <int CPW, int WPC>
 static void launch_lat_shape(hipStream_t s, int nitems, int n_wg, const int* order, const IcpCluster* cl, IcpState* st, unsigned long long* accf,
-                             const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy, IcpParams prm) {
-    hipLaunchKernelGGL((k_icp_lat<CPW, WPC>), dim3(n_wg), dim3(CPW * WPC * WAVE), 0, s, nitems, order, cl, st, accf, lats, src, src0, queue, busy, prm);
+                             const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy, unsigned long long* busy_out,
+                             IcpParams prm) {
+    hipLaunchKernelGGL((k_icp_lat<CPW, WPC>), dim3(n_wg), dim3(CPW * WPC * WAVE), 0, s, nitems, order, cl, st, accf, lats, src, src0, queue, busy, busy_out, prm);
 }
 void launch_icp_lat(hipStream_t s, int nitems, int cpw, int wpc, int n_wg, const int* order, const IcpCluster* cl, IcpState* st,
-                    unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy, IcpParams prm) {
+                    unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy,
+                    unsigned long long* busy_out, IcpParams prm) {
     if (nitems <= 0 || n_wg <= 0) return;
-#define CD_LAT_CASE(C, W) if (cpw == C && wpc == W) return launch_lat_shape<C, W>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, prm);
+#define CD_LAT_CASE(C, W) if (cpw == C && wpc == W) return launch_lat_shape<C, W>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, busy_out, prm);
     CD_LAT_CASE(1, 1) CD_LAT_CASE(1, 2) CD_LAT_CASE(1, 4) CD_LAT_CASE(1, 8) CD_LAT_CASE(1, 16)
     CD_LAT_CASE(2, 1) CD_LAT_CASE(2, 2) CD_LAT_CASE(2, 4)
     CD_LAT_CASE(4, 1) CD_LAT_CASE(4, 2) CD_LAT_CASE(4, 4)
     CD_LAT_CASE(8, 1) CD_LAT_CASE(8, 2)
 #undef CD_LAT_CASE
-    launch_lat_shape<1, 4>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, prm);
+    launch_lat_shape<1, 4>(s, nitems, n_wg, order, cl, st, accf, lats, src, src0, queue, busy, busy_out, prm);
 }
 void launch_lat_nn(hipStream_t s, const IcpLattice* lat, const float4* q, int n, int* out_idx, float* out_d2) {
     if (n <= 0) return;

@@ -108,7 +108,7 @@ void launch_icp_cluster(hipStream_t s, int ncl, const int* order, const IcpClust
 // k_icp_lat.hip : templates that are unions of axis-aligned lattices (IcpLattice) - closed-form nearest neighbour
 void launch_icp_lat(hipStream_t s, int nitems, int cpw, int wpc, int n_wg, const int* order, const IcpCluster* cl, IcpState* st,
                     unsigned long long* accf, const IcpLattice* lats, float4* src, const float4* src0, int* queue, unsigned long long* busy,
-                    IcpParams prm);
+                    unsigned long long* busy_out, IcpParams prm);
 void launch_lat_nn(hipStream_t s, const IcpLattice* lat, const float4* q, int n, int* out_idx, float* out_d2);
 
 }  // namespace cd

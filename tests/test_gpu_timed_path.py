@@ -219,11 +219,13 @@ def test_pipe_big_handover_of_running_clusters(O, monkeypatch):
     assert np.array_equal(got["0"][0], got["1"][0])
 
 
-@pytest.mark.parametrize("switch", ["CUBOID_COPY_KERNELS", "CUBOID_ZERO_ONCE", "CUBOID_CROP_DIRECT", "CUBOID_CENTROID_LANES"])
+@pytest.mark.parametrize("switch", ["CUBOID_COPY_KERNELS", "CUBOID_ZERO_ONCE", "CUBOID_CROP_DIRECT", "CUBOID_CENTROID_LANES", "CUBOID_MIRROR_READS",
+                                    "CUBOID_MIRROR_WRITES", "CUBOID_ICP_DIRECT"])
 def test_plumbing_switches_leave_the_records_unchanged(template, switch, monkeypatch):
     """Round 5 moved the small pinned <-> device transfers from hipMemcpyAsync to copy kernels on the context's stream (batched:
     one launch per stage), all zero fills of a fused call into one launch, the cropped points out of the arena (run records point
-    into the input) and the centroid sums onto one lane per voxel.  Each has a switch back to the previous form: the records of a
+    into the input), the centroid sums onto one lane per voxel, and let kernels read the host's pinned per-frame words and write
+    the FrameState mirror and the ICP results themselves.  Each has a switch back to the previous form: the records of a
     fused batch call must be the same bytes either way (the default form is compared with the oracle by every other test)."""
     F = 6
     frames = _render(40, F)
