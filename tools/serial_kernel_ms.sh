@@ -13,7 +13,7 @@ import csv
 rows=list(csv.DictReader(open("$R/gpurun_out/serial_kernel_stats.csv")))
 tot=0
 for r in rows:
-    n=r["Name"].split("(")[0].replace("cd::","")
+    n=r["Name"].split("(")[0].replace("cd::","").replace("void ","")   # (templated kernels are listed as "void cd::k_...<...>")
     per_batch=float(r["TotalDurationNs"])/8/1e6
     tot+=per_batch if n.startswith("k_") else 0
     print("%-28s calls %5s  avg %9.1f us  per batch %7.3f ms" % (n, r["Calls"], float(r["AverageNs"])/1e3, per_batch))
