@@ -24,8 +24,9 @@
 //       reaches the minimum.
 // Checked against brute force with the oracle's arithmetic on all five reference cuboid templates incl. the 21 400-point
 // six-face one: tests/test_gpu_lattice.py (near, far, mid-cell, +-300 m along a face normal - a tie walk across the whole face).
-// ~100 vector instructions per query with no divergence, against ~2400 per 64-query pass of the pruned searches, and no
-// 116 KB template image: a workgroup needs <= 12 KB of LDS, so ICP workgroups stop monopolising CUs.
+// ~215 vector instructions per pass of 64 queries (transform 18, three axes 51, faces 52, tie filter 13, moment terms 67, loop 14),
+// no divergence outside the rare tie walk, against ~2400 per pass of the pruned searches - and no 116 KB template image: a slot
+// needs 8.7 KB of LDS, so ICP workgroups stop monopolising CUs.
 //
 // Launch shape: a workgroup keeps one or several clusters going, every cluster's whole ICP inside it (k_icp_lat<CPW, WPC> below).
 // No MFMA: there is no dense contraction here (3x3 matrices only).
