@@ -15,7 +15,10 @@ constexpr int TILE = BLOCK * ITEMS;        // 2048 elements; wave w owns [w*512,
 constexpr int WAVE_SPAN = WAVE * ITEMS;    // 512
 constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
-constexpr int SORT_BLOCK = 1024;           // the sort's tiles are 4x larger than the ordered tiles of the other stages: a
+#ifndef CD_SORT_BLOCK
+#define CD_SORT_BLOCK 1024
+#endif
+constexpr int SORT_BLOCK = CD_SORT_BLOCK;           // the sort's tiles are 4x larger than the ordered tiles of the other stages: a
 constexpr int SORT_TILE = SORT_BLOCK * ITEMS;   // (digit, tile) run of the scatter is then ~32 pairs = full 128-B lines
 constexpr int KICP = CD_MAX_CLUSTERS_PER_FRAME;  // clusters per frame that get ICP
 constexpr int FIX_SHIFT = 32;              // canonical rule C4

@@ -245,8 +245,48 @@ int with_scan_retry(cd_context* c, Fn&& fn) {
     return st;
 }
 
+#ifdef CD_ALLOC_GUARD
+// Debug build (make VARIANT=guard FLAGS_EXTRA=-DCD_ALLOC_GUARD=262144): every device allocation of the library gets that many
+// bytes of 0xA5 behind it, checked when it is freed - a kernel that WRITES past the end of an array is named on stderr instead
+// of corrupting its neighbour (or faulting only when the neighbour happens to be unmapped); a kernel that only READS past the
+// end stops faulting and leaves the guards intact, which says as much.
+struct GuardEntry { void* p; size_t bytes; std::string name; };
+static std::mutex g_guard_mu;
+static std::vector<GuardEntry> g_guards;
+static hipError_t guard_malloc(void** p, size_t bytes, const char* name) {
+    const hipError_t e = hipMalloc(p, bytes + (size_t)CD_ALLOC_GUARD);
+    if (e != hipSuccess) return e;
+    (void)hipMemset((char*)*p + bytes, 0xA5, (size_t)CD_ALLOC_GUARD);
+    std::lock_guard<std::mutex> lk(g_guard_mu);
+    g_guards.push_back(GuardEntry{*p, bytes, name});
+    return hipSuccess;
+}
+static hipError_t guard_free(void* p) {
+    GuardEntry ge{nullptr, 0, ""};
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        for (size_t i = 0; i < g_guards.size(); ++i)
+            if (g_guards[i].p == p) { ge = g_guards[i]; g_guards.erase(g_guards.begin() + (long)i); break; }
+    }
+    if (ge.p) {
+        std::vector<unsigned char> h((size_t)CD_ALLOC_GUARD);
+        (void)hipDeviceSynchronize();
+        if (hipMemcpy(h.data(), (char*)p + ge.bytes, h.size(), hipMemcpyDeviceToHost) == hipSuccess) {
+            size_t first = h.size(), last = 0, bad = 0;
+            for (size_t i = 0; i < h.size(); ++i) if (h[i] != 0xA5) { if (first == h.size()) first = i; last = i; ++bad; }
+            if (bad) std::fprintf(stderr, "cuboid_hip GUARD: %s (%zu bytes) was written past its end: %zu bytes between +%zu and +%zu\n", ge.name.c_str(), ge.bytes, bad, first, last);
+        }
+    }
+    return (hipFree)(p);
+}
+#define hipFree(p) guard_free(p)
+template <class Tp>
+hipError_t dalloc_named(Tp** p, size_t n, const char* name) { return guard_malloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp), name); }
+#define dalloc(p, n) dalloc_named(p, n, #p)
+#else
 template <class Tp>
 hipError_t dalloc(Tp** p, size_t n) { return hipMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp)); }
+#endif
 template <class Tp>
 hipError_t halloc(Tp** p, size_t n) { return hipHostMalloc((void**)p, std::max<size_t>(n, 1) * sizeof(Tp), hipHostMallocDefault); }
 
@@ -305,7 +345,11 @@ int ensure_input(cd_context* c, size_t bytes) {
     if (c->d_in) hipFree(c->d_in);
     c->d_in = nullptr;
     c->d_in_bytes = 0;
+#ifdef CD_ALLOC_GUARD
+    HIPCHK(c, guard_malloc((void**)&c->d_in, bytes, "d_in"));
+#else
     HIPCHK(c, hipMalloc((void**)&c->d_in, bytes));
+#endif
     c->d_in_bytes = bytes;
     return CD_OK;
 }
