@@ -214,6 +214,17 @@ __host__ __device__ __forceinline__ float ord2f(uint32_t o) {
 // wave ballot of a BOOL: HIP's __ballot(int) first turns a lane mask that is already in SGPRs (e.g. a && of two compares)
 // into a 0/1 vector and compares it again - two vector instructions per loop condition in the ICP search loops
 __device__ __forceinline__ uint64_t ballot64(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// Debug build (-DCD_BOUNDS): CD_IN_RANGE(cond, code) is `cond`, and a false one is reported by a device printf (check number,
+// workgroup, thread) - the access it guards is then skipped instead of faulting.  Without the flag: true.
+#ifdef CD_BOUNDS
+__device__ __forceinline__ bool cd_in_range(bool ok, unsigned code) {
+    if (!ok) printf("cuboid_hip BOUNDS: check %u failed in workgroup %u thread %u\n", code, (unsigned)blockIdx.x, (unsigned)threadIdx.x);
+    return ok;
+}
+#define CD_IN_RANGE(cond, code) cd::cd_in_range((cond), (code))
+#else
+#define CD_IN_RANGE(cond, code) true
+#endif
 // R rows of a wave's tile, ALL loaded before any is used: element first + j * 64 of an array of n >= 1 elements, the index
 // clamped into the array instead of tested (callers still ignore rows past n).  A load inside `if (e < n)` is followed by
 // s_waitcnt vmcnt(0) before the next row's load is even issued - one memory round trip per row, eight in a row
@@ -305,7 +316,7 @@ __device__ __forceinline__ int take_ticket(int* counter, int tickets, int* s_tic
     if (threadIdx.x == 0) {
         const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (t == tickets - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        *s_ticket = t;
+        *s_ticket = CD_IN_RANGE(t >= 0 && t < tickets, 1u) ? t : 0;
     }
     __syncthreads();
     return *s_ticket;

@@ -198,8 +198,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
         if (e < n) {
             const uint32_t d = (key[j] >> shift) & (RADIX - 1);
             const uint32_t lp = s_bstart[d] + s_wh[w][d] + rank[j];
-            s_k[lp] = key[j];
-            s_v[lp] = val[j];
+            if (CD_IN_RANGE(lp < (uint32_t)SORT_TILE, 2u)) {
+                s_k[lp] = key[j];
+                s_v[lp] = val[j];
+            }
         }
     }
     __syncthreads();
@@ -212,8 +214,10 @@ __global__ void __launch_bounds__(SORT_BLOCK) k_radix_scatter(const uint32_t* __
             const uint32_t k = s_k[lp];
             const uint32_t d = (k >> shift) & (RADIX - 1);
             const uint32_t dst = s_goff[d] + ((uint32_t)lp - s_bstart[d]);
-            kout[fbase + dst] = k;
-            vout[fbase + dst] = s_v[lp];
+            if (CD_IN_RANGE(dst < (uint32_t)n, 3u)) {
+                kout[fbase + dst] = k;
+                vout[fbase + dst] = s_v[lp];
+            }
         }
     }
     SORT_PHASE(3)

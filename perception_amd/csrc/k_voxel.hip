@@ -468,7 +468,7 @@ __global__ void __launch_bounds__(BLOCK) k_crop_runs(const char* __restrict__ in
             const int ro = rpos + __popcll(heads[j] & lt);
             const uint32_t key = s_key[w * WAVE_SPAN + j * WAVE + lane];
             s_rk[ro - rexcl0] = (unsigned short)(w * WAVE_SPAN + j * WAVE + lane);
-            if (ro < pitch) {
+            if (ro < pitch && CD_IN_RANGE(ro >= 0, 5u)) {
                 rkeys[obase + ro] = key;
                 rvals[obase + ro] = (uint32_t)(DIRECT ? base + j * WAVE + lane : r) | ((uint32_t)(next - lane) << RUN_SHIFT_C);
             }
@@ -874,7 +874,7 @@ __global__ void __launch_bounds__(BLOCK) k_voxel_centroid_lanes(const uint32_t* 
                 const int idx = i + t;
                 const int off = idx >= c3 ? s3 : (idx >= c2 ? s2 : (idx >= c1 ? s1 : s0));
                 P[t] = z;
-                if (idx < tot) P[t] = pts[off + idx];
+                if (idx < tot && CD_IN_RANGE(off + idx >= 0 && off + idx < pts_pitch, 4u)) P[t] = pts[off + idx];
             }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
